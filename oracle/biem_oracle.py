@@ -1,0 +1,606 @@
+"""CPU oracle for the biem() assembly-and-solve hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This module is the checker, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+The product path (``biem_helmholtz_sphere_amd``) never imports anything from here.
+
+It is a NumPy/SciPy restatement of the algorithm of the reference
+(ultrasphere-dev/biem-helmholtz-sphere v1.2.0):
+
+* the linear system in closed form           reference ``_biem.py:511-529``
+* which factor multiplies rows / columns     reference ``_biem.py:723-792`` (code, not docstring)
+* the right-hand side                        reference ``_biem.py:611-639``
+* the dense solve                            reference ``_biem.py:797``
+* the single-ball shortcut                   reference ``_biem.py:648-691``
+* field evaluation (near / far, NaN mask)    reference ``_biem.py:896-976``
+* plane wave / point source                  reference ``_biem.py:329-450``
+
+The arithmetic the reference delegates to un-vendored PyPI packages (``ultrasphere`` 2.0.4,
+``ultrasphere-harmonics`` 1.3.0, ``batch-tensorsolve`` 1.0.1; pins in the reference's ``uv.lock``)
+is restated from published mathematics:
+
+* d-dimensional spherical Bessel functions  z_n(x) = sqrt(pi/2) Z_{n+d/2-1}(x) / x^{d/2-1}
+* orthonormal hyperspherical harmonics of the coordinate trees ``a`` (d=2), ``ba`` (d=3), ``bba`` (d=4)
+* the tensor Gauss rule used for the boundary data (type-a node: 2 n_end equispaced points,
+  type-b node: n_end-point Gauss-Jacobi((s-1)/2,(s-1)/2))
+* the exact (S|R) translation coefficients
+    (S|R)_{n'p'->np}(t) = C_d sum_{n''p''} i^{n+n''-n'} h_{n''}(k|t|) Y_{n''p''}(t^)
+                               * int Y_{n'p'} conj(Y_np) conj(Y_{n''p''}) dOmega ,  C_d = (2 pi)^{d/2} sqrt(2/pi)
+
+PINNING: ``tests/test_oracle_golden.py`` checks this oracle against the golden ``u_scat`` values the
+reference commits (``jascome/jascome_output.csv``, ``accuracy/accuracy_k_ba.csv``,
+``accuracy/accuracy_k_a.csv``, ``accuracy/accuracy_n_balls_a.csv``, README doctest), copied as data
+fixtures to ``tests/golden``.  Quantities no reference fixture constrains (order of the ``harm`` axis of
+``density`` / ``matrix``, Robin rows, far field, ``kind="inner"``, point source) are "parity unpinned":
+for them this oracle is an independent exact-maths statement, cross-checked by physical self-tests.
+
+The order of the flattened ``harm`` axis is this project's own choice (the reference's is decided inside
+un-vendored ``ush.flatten_harmonics``):
+    a   : m = 0, 1, .., n_end-1, -(n_end-1), .., -1           (degree n = |m|)
+    ba  : (n, m), n-major, m = -n..n                          index n^2 + n + m
+    bba : (n, l, m), n-major, then l = 0..n, then m = -l..l
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from functools import lru_cache
+
+import numpy as np
+from scipy import special as sp
+
+__all__ = [
+    "Tree", "tree", "radial", "solve_biem", "uscat", "plane_wave", "point_source",
+    "grid_centers", "OracleResult",
+]
+
+# --------------------------------------------------------------------------------------
+# d-dimensional spherical Bessel / Hankel functions  
+# --------------------------------------------------------------------------------------
+
+
+def radial(nmax: int, d: int, x: float):
+    """Return (j, y, jp, yp): arrays n = 0..nmax of z_n^{(d)}(x) and derivatives (real x > 0).
+
+    z_n^{(d)}(x) = sqrt(pi/2) Z_{n + d/2 - 1}(x) / x^{d/2 - 1};   z_n' = (n/x) z_n - z_{n+1}.
+    """
+    x = float(x)
+    n = np.arange(nmax + 2)
+    if d == 3:
+        j = sp.spherical_jn(n, x)
+        y = sp.spherical_yn(n, x)
+    else:
+        nu = n + d / 2.0 - 1.0
+        pref = math.sqrt(math.pi / 2.0) / x ** (d / 2.0 - 1.0)
+        j = pref * sp.jv(nu, x)
+        y = pref * sp.yv(nu, x)
+    nn = n[:-1]
+    jp = nn / x * j[:-1] - j[1:]
+    yp = nn / x * y[:-1] - y[1:]
+    return j[:-1], y[:-1], jp, yp
+
+
+# --------------------------------------------------------------------------------------
+# Orthonormal building blocks
+# --------------------------------------------------------------------------------------
+
+
+def _pbar(nmax: int, x: np.ndarray) -> np.ndarray:
+    """Orthonormal associated Legendre  P[n, m, ...]  (0<=m<=n<=nmax), int_{-1}^{1} P^2 dx = 1.
+
+    No Condon-Shortley phase (positive leading coefficient).
+    """
+    x = np.asarray(x, dtype=np.float64)
+    s = np.sqrt(np.maximum(0.0, 1.0 - x * x))
+    P = np.zeros((nmax + 1, nmax + 1) + x.shape)
+    P[0, 0] = math.sqrt(0.5)
+    for m in range(1, nmax + 1):
+        P[m, m] = math.sqrt((2 * m + 1) / (2 * m)) * s * P[m - 1, m - 1]
+    for m in range(0, nmax):
+        P[m + 1, m] = math.sqrt(2 * m + 3) * x * P[m, m]
+        for n in range(m + 2, nmax + 1):
+            a = math.sqrt((4 * n * n - 1) / (n * n - m * m))
+            b = math.sqrt(((n - 1) ** 2 - m * m) / (4 * (n - 1) ** 2 - 1))
+            P[n, m] = a * (x * P[n - 1, m] - b * P[n - 2, m])
+    return P
+
+
+def _gbar(kmax: int, lam: float, x: np.ndarray) -> np.ndarray:
+    """Orthonormal Gegenbauer p_k^{(lam)}(x), k=0..kmax, weight (1-x^2)^{lam-1/2} on [-1,1]."""
+    x = np.asarray(x, dtype=np.float64)
+    p = np.zeros((kmax + 1,) + x.shape)
+    h0 = math.sqrt(math.pi) * math.exp(math.lgamma(lam + 0.5) - math.lgamma(lam + 1.0))
+    p[0] = 1.0 / math.sqrt(h0)
+
+    def a(k):  # x p_{k-1} = a_k p_k + a_{k-1} p_{k-2}
+        return 0.5 * math.sqrt(k * (k + 2 * lam - 1) / ((k + lam - 1) * (k + lam)))
+
+    if kmax >= 1:
+        p[1] = x * p[0] / a(1)
+    for k in range(2, kmax + 1):
+        p[k] = (x * p[k - 1] - a(k - 1) * p[k - 2]) / a(k)
+    return p
+
+
+def _gauss_legendre(n):
+    t, w = sp.roots_legendre(n)
+    return t, w
+
+
+def _gauss_cheb2(n):
+    """Gauss-Jacobi(1/2,1/2): weight sqrt(1-t^2)."""
+    i = np.arange(1, n + 1)
+    th = i * math.pi / (n + 1)
+    return np.cos(th), math.pi / (n + 1) * np.sin(th) ** 2
+
+
+# --------------------------------------------------------------------------------------
+# Coordinate trees  
+# --------------------------------------------------------------------------------------
+
+
+@dataclass(frozen=True)
+class Tree:
+    name: str
+    d: int
+
+    # ---- index sets -------------------------------------------------------------------
+    def index(self, n_end: int):
+        """List of harmonic labels of degree < n_end in this project's canonical order."""
+        if self.name == "a":
+            return [(m,) for m in list(range(0, n_end)) + list(range(-(n_end - 1), 0))]
+        if self.name == "ba":
+            return [(n, m) for n in range(n_end) for m in range(-n, n + 1)]
+        if self.name == "bba":
+            return [(n, l, m) for n in range(n_end) for l in range(n + 1) for m in range(-l, l + 1)]
+        raise NotImplementedError(self.name)
+
+    def degrees(self, n_end: int) -> np.ndarray:
+        if self.name == "a":
+            return np.array([abs(t[0]) for t in self.index(n_end)])
+        return np.array([t[0] for t in self.index(n_end)])
+
+    def n_harm(self, n_end: int) -> int:
+        return len(self.index(n_end))
+
+    # ---- harmonics ---------------------------------------------------------------------
+    def harmonics(self, u: np.ndarray, n_end: int) -> np.ndarray:
+        """Y[h, P] at unit vectors u[P, d] for all labels of degree < n_end."""
+        u = np.asarray(u, dtype=np.float64)
+        idx = self.index(n_end)
+        P = u.shape[0]
+        out = np.zeros((len(idx), P), dtype=np.complex128)
+        if self.name == "a":
+            phi = np.arctan2(u[:, 1], u[:, 0])
+            for h, (m,) in enumerate(idx):
+                out[h] = np.exp(1j * m * phi) / math.sqrt(2 * math.pi)
+            return out
+        if self.name == "ba":
+            ct = np.clip(u[:, 0], -1.0, 1.0)
+            phi = np.arctan2(u[:, 2], u[:, 1])
+            Pb = _pbar(max(n_end - 1, 0), ct)
+            for h, (n, m) in enumerate(idx):
+                out[h] = Pb[n, abs(m)] * np.exp(1j * m * phi) / math.sqrt(2 * math.pi)
+            return out
+        if self.name == "bba":
+            c0 = np.clip(u[:, 0], -1.0, 1.0)
+            s0 = np.sqrt(np.maximum(0.0, 1.0 - c0 * c0))
+            rest = np.sqrt(u[:, 1] ** 2 + u[:, 2] ** 2 + u[:, 3] ** 2)
+            c1 = np.where(rest > 0, u[:, 1] / np.where(rest > 0, rest, 1.0), 1.0)
+            c1 = np.clip(c1, -1.0, 1.0)
+            phi = np.arctan2(u[:, 3], u[:, 2])
+            Pb = _pbar(max(n_end - 1, 0), c1)
+            G = {l: _gbar(n_end - 1 - l, l + 1.0, c0) for l in range(n_end)}
+            for h, (n, l, m) in enumerate(idx):
+                out[h] = (s0 ** l) * G[l][n - l] * Pb[l, abs(m)] * np.exp(1j * m * phi) / math.sqrt(2 * math.pi)
+            return out
+        raise NotImplementedError(self.name)
+
+    # ---- quadrature (the rule ush.expand(n=n_end) uses) -------------------------
+    def quadrature(self, n: int):
+        """Unit vectors y[Q, d] and weights w[Q] of the n-rule (tensor Gauss)."""
+        phi = np.arange(2 * n) * (math.pi / n)
+        wphi = np.full(2 * n, math.pi / n)
+        if self.name == "a":
+            return np.stack([np.cos(phi), np.sin(phi)], axis=-1), wphi
+        if self.name == "ba":
+            t, wt = _gauss_legendre(n)
+            T, PH = np.meshgrid(t, phi, indexing="ij")
+            W = wt[:, None] * wphi[None, :]
+            S = np.sqrt(1 - T * T)
+            y = np.stack([T, S * np.cos(PH), S * np.sin(PH)], axis=-1).reshape(-1, 3)
+            return y, W.reshape(-1)
+        if self.name == "bba":
+            t0, w0 = _gauss_cheb2(n)
+            t1, w1 = _gauss_legendre(n)
+            T0, T1, PH = np.meshgrid(t0, t1, phi, indexing="ij")
+            W = w0[:, None, None] * w1[None, :, None] * wphi[None, None, :]
+            S0 = np.sqrt(1 - T0 * T0)
+            S1 = np.sqrt(1 - T1 * T1)
+            y = np.stack([T0, S0 * T1, S0 * S1 * np.cos(PH), S0 * S1 * np.sin(PH)], axis=-1).reshape(-1, 4)
+            return y, W.reshape(-1)
+        raise NotImplementedError(self.name)
+
+
+_TREES = {"a": Tree("a", 2), "ba": Tree("ba", 3), "bba": Tree("bba", 4)}
+
+
+def tree(name: str) -> Tree:
+    return _TREES[name]
+
+
+# --------------------------------------------------------------------------------------
+# Translation coefficients (S|R)  
+# --------------------------------------------------------------------------------------
+
+
+@lru_cache(maxsize=8)
+def _sr_tables(name: str, n_end: int):
+    """Quadrature data for :func:`translation_SR_quadrature` (rule exact for degree <= 4 n_end - 4)."""
+    tr = tree(name)
+    yq, wq = tr.quadrature(2 * n_end)
+    Yq = tr.harmonics(yq, n_end)                 # [H, Q]
+    Yq2 = tr.harmonics(yq, 2 * n_end - 1)        # [H2, Q]
+    deg = tr.degrees(n_end)
+    deg2 = tr.degrees(2 * n_end - 1)
+    return yq, wq, Yq, Yq2, deg, deg2
+
+
+def translation_SR_quadrature(tr: Tree, n_end: int, k: float, t: np.ndarray) -> np.ndarray:
+    """Closed form with the triple integrals done implicitly by one quadrature.
+
+    Mathematically identical to :func:`translation_SR` but numerically usable only for small n_end
+    (the huge h_{n''} terms cancel through quadrature rounding); kept as an independent cross-check.
+    """
+    yq, wq, Yq, Yq2, deg, deg2 = _sr_tables(tr.name, n_end)
+    d = tr.d
+    Cd = (2 * math.pi) ** (d / 2.0) * math.sqrt(2.0 / math.pi)
+    r = float(np.linalg.norm(t))
+    j, y, _, _ = radial(2 * n_end - 2, d, k * r)
+    hn = j + 1j * y
+    Yt = tr.harmonics((np.asarray(t, dtype=np.float64) / r)[None, :], 2 * n_end - 1)[:, 0]  # [H2]
+    F = ((1j ** deg2) * hn[deg2] * Yt) @ np.conj(Yq2)               # [Q]
+    ph = 1j ** deg
+    A = (Yq * (wq * F)[None, :]) @ np.conj(Yq).T                    # [h', h]
+    return Cd * (np.conj(ph)[:, None] * A * ph[None, :])
+
+
+@lru_cache(maxsize=8)
+def _gaunt3(n_end: int):
+    """G3[h', h, n''] = int Y_{n'm'} conj(Y_{nm}) conj(Y_{n'', m'-m}) dOmega  over S^2 (real).
+
+    Gauss-Legendre with 2 n_end nodes is exact (integrand degree <= 4 n_end - 4); entries excluded by
+    the selection rules (triangle, parity, |m'-m| <= n'') are set to exactly zero.
+    """
+    tr = tree("ba")
+    idx = tr.index(n_end)
+    H = len(idx)
+    n2 = 2 * n_end - 1
+    t, w = _gauss_legendre(2 * n_end)
+    Pb = _pbar(n2 - 1, t)                                           # [n, m, q]
+    nn = np.array([i[0] for i in idx])
+    mm = np.array([i[1] for i in idx])
+    Ph = Pb[nn, np.abs(mm), :]                                      # [H, q]
+    A = Ph[:, None, :] * Ph[None, :, :] * w[None, None, :]          # [h', h, q]
+    mu = np.abs(mm[:, None] - mm[None, :])
+    G = np.zeros((H, H, n2))
+    for a in range(n2):
+        msk = mu == a
+        if msk.any():
+            G[msk, :] = A[msk, :] @ Pb[:, a, :].T
+    G /= math.sqrt(2 * math.pi)
+    n3 = np.arange(n2)[None, None, :]
+    ok = (n3 >= np.abs(nn[:, None, None] - nn[None, :, None])) & (n3 <= nn[:, None, None] + nn[None, :, None])
+    ok &= ((nn[:, None, None] + nn[None, :, None] + n3) % 2 == 0) & (n3 >= mu[:, :, None])
+    G[~ok] = 0.0
+    return G, nn, mm
+
+
+@lru_cache(maxsize=8)
+def _theta4(n_end: int):
+    """A4[(n'l'), (n l), n'', l''] = int Abar_{n'l'} Abar_{nl} Abar_{n''l''} sin^2 dtheta (type-b root of bba)."""
+    n2 = 2 * n_end - 1
+    t, w = _gauss_cheb2(2 * n_end)                                  # weight sqrt(1-t^2) = one sin of sin^2 dtheta
+    s = np.sqrt(1 - t * t)
+    Ab = np.zeros((n2, n2, len(t)))                                 # [n, l, q]
+    for l in range(n2):
+        g = _gbar(n2 - 1 - l, l + 1.0, t)
+        for n in range(l, n2):
+            Ab[n, l] = s ** l * g[n - l]
+    nl = [(n, l) for n in range(n_end) for l in range(n + 1)]
+    An = np.array([Ab[n, l] for (n, l) in nl])                      # [NL, q]
+    A4 = np.einsum("aq,bq,nlq,q->abnl", An, An, Ab, w, optimize=True)
+    A4[np.abs(A4) < 1e-14] = 0.0          # quadrature noise on entries that vanish by the selection rules
+    return A4, nl, Ab
+
+
+def translation_SR(tr: Tree, n_end: int, k: float, t: np.ndarray) -> np.ndarray:
+    """SR[h', h] = (S|R)_{h' -> h}(t): S_{h'}(r + t) = sum_h SR[h', h] R_h(r) for |r| < |t|.
+
+    Exact closed form of SURVEY A.5 with pre-tabulated triple integrals.
+    """
+    t = np.asarray(t, dtype=np.float64)
+    d = tr.d
+    r = float(np.linalg.norm(t))
+    if tr.name == "a":
+        return translation_SR_2d_graf(n_end, k, t)
+    Cd = (2 * math.pi) ** (d / 2.0) * math.sqrt(2.0 / math.pi)
+    n2 = 2 * n_end - 1
+    j, y, _, _ = radial(n2 - 1, d, k * r)
+    hn = j + 1j * y
+    u = t / r
+    if tr.name == "ba":
+        G, nn, mm = _gaunt3(n_end)
+        ct = min(1.0, max(-1.0, u[0]))
+        phi = math.atan2(u[2], u[1])
+        Pb = _pbar(n2 - 1, np.array(ct))                            # [n'', mu]
+        mus = np.arange(-(n2 - 1), n2)
+        T = hn[:, None] * Pb[:, np.abs(mus)] * np.exp(1j * mus * phi)[None, :] / math.sqrt(2 * math.pi)  # [n'', mu]
+        mu = mm[:, None] - mm[None, :] + (n2 - 1)
+        Tg = T[:, mu]                                               # [n'', h', h]
+        n3 = np.arange(n2)[:, None, None]
+        sign = np.real(1j ** ((nn[None, None, :] + n3 - nn[None, :, None]) % 4 + 0))
+        # i^{n+n''-n'} is real wherever G != 0 (parity rule)
+        return Cd * np.sum(np.moveaxis(G, -1, 0) * sign * Tg, axis=0)
+    if tr.name == "bba":
+        A4, nl, _ = _theta4(n_end)
+        G3, ll3, mm3 = _gaunt3(n_end)                               # labels (l, m), l < n_end
+        idx = tr.index(n_end)
+        H = len(idx)
+        nlpos = {p: i for i, p in enumerate(nl)}
+        lmpos = {(l, m): i for i, (l, m) in enumerate(zip(ll3.tolist(), mm3.tolist()))}
+        a_of = np.array([nlpos[(n, l)] for (n, l, m) in idx])
+        g_of = np.array([lmpos[(l, m)] for (n, l, m) in idx])
+        nn = np.array([i[0] for i in idx])
+        mm = np.array([i[2] for i in idx])
+        # V[n'', l'', mu] = h_{n''} Abar_{n''l''}(theta0_t) Y3_{l'' mu}(theta1_t, phi_t)
+        c0 = min(1.0, max(-1.0, u[0]))
+        s0 = math.sqrt(max(0.0, 1 - c0 * c0))
+        rest = math.sqrt(u[1] ** 2 + u[2] ** 2 + u[3] ** 2)
+        c1 = u[1] / rest if rest > 0 else 1.0
+        phi = math.atan2(u[3], u[2])
+        Pb = _pbar(n2 - 1, np.array(min(1.0, max(-1.0, c1))))
+        mus = np.arange(-(n2 - 1), n2)
+        Y3 = Pb[:, np.abs(mus)] * np.exp(1j * mus * phi)[None, :] / math.sqrt(2 * math.pi)     # [l'', mu]
+        Ab = np.zeros((n2, n2))
+        for l in range(n2):
+            g = _gbar(n2 - 1 - l, l + 1.0, np.array(c0))
+            for n in range(l, n2):
+                Ab[n, l] = s0 ** l * g[n - l]
+        V = hn[:, None, None] * Ab[:, :, None] * Y3[None, :, :]       # [n'', l'', mu]
+        SR = np.zeros((H, H), dtype=np.complex128)
+        n3 = np.arange(n2)
+        for hp in range(H):
+            mu = mm[hp] - mm + (n2 - 1)                               # [h]
+            sign = np.real(1j ** ((nn[None, :] + n3[:, None] - nn[hp]) % 4))    # [n'', h]
+            Kq = A4[a_of[hp], a_of]                                   # [h, n'', l'']
+            G3r = G3[g_of[hp], g_of]                                  # [h, l'']   (only l'' < n2 of the n_end table)
+            Vg = V[:, :, mu]                                          # [n'', l'', h]
+            # G3 table from _gaunt3(n_end) has l'' < 2 n_end - 1 as required
+            SR[hp] = np.einsum("hnl,hl,nh,nlh->h", Kq, G3r, sign, Vg, optimize=True)
+        return Cd * SR
+    raise NotImplementedError(tr.name)
+
+
+def translation_SR_2d_graf(n_end: int, k: float, t: np.ndarray) -> np.ndarray:
+    """d = 2 closed form (Graf) in the |m|-degree basis; cross-check of :func:`translation_SR`."""
+    ms = np.array([m for (m,) in tree("a").index(n_end)])
+    r = float(np.hypot(t[0], t[1]))
+    phi = math.atan2(t[1], t[0])
+    mu = ms[:, None] - ms[None, :]                                   # m' - m
+    H = sp.hankel1(np.abs(mu), k * r)
+    sign = 1j ** (np.abs(ms)[None, :] + np.abs(mu) - np.abs(ms)[:, None])
+    return sign * H * np.exp(1j * mu * phi)
+
+
+# --------------------------------------------------------------------------------------
+# Incident fields  (reference _biem.py:329-450)
+# --------------------------------------------------------------------------------------
+
+
+def plane_wave(k: float, direction):
+    dvec = np.asarray(direction, dtype=np.float64)
+    dvec = dvec / np.linalg.norm(dvec)
+
+    def u(x):  # x[..., d]
+        return np.exp(1j * k * (x @ dvec))
+
+    def grad(x):
+        return 1j * k * dvec * np.exp(1j * k * (x @ dvec))[..., None]
+
+    return u, grad
+
+
+def point_source(k: float, source, n: int):
+    src = np.asarray(source, dtype=np.float64)
+    d = src.shape[0]
+
+    def _h(r, der=False):
+        out = np.empty(r.shape, dtype=np.complex128)
+        for i, ri in np.ndenumerate(r):
+            j, y, jp, yp = radial(n, d, k * ri)
+            out[i] = (jp[n] + 1j * yp[n]) if der else (j[n] + 1j * y[n])
+        return out
+
+    def u(x):
+        return _h(np.linalg.norm(x - src, axis=-1))
+
+    def grad(x):
+        rel = x - src
+        r = np.linalg.norm(rel, axis=-1)
+        return (k * _h(r, True) / r)[..., None] * rel
+
+    return u, grad
+
+
+# --------------------------------------------------------------------------------------
+# Assembly + solve
+# --------------------------------------------------------------------------------------
+
+
+@dataclass
+class OracleResult:
+    tree: Tree
+    n_end: int
+    k: float
+    eta: float
+    centers: np.ndarray        # [B, d]
+    radii: np.ndarray          # [B]
+    density: np.ndarray | None  # [B, H]   reference scaling  phi = c / blc
+    coef: np.ndarray | None     # [B, H]   outgoing-wave coefficients c
+    matrix: np.ndarray | None   # [B, H, B, H]  reference scaling
+    rhs: np.ndarray | None      # [B, H]
+    kind: str = "outer"
+
+
+def ball_tables(tr: Tree, n_end: int, k: float, eta: float, rho: float, alpha: complex, beta: complex):
+    """Per-degree row/column factors of one ball: gj, gh, blc (arrays n = 0..n_end-1).
+
+    gj = alpha j_n + beta k j_n'   (reference _biem.py:770-788)
+    gh = alpha h_n + beta k h_n'   (reference _biem.py:749-766)
+    blc = dlc - i eta slc,  slc = i k^{d-2} rho^{d-1} j_n, dlc = i k^{d-1} rho^{d-1} j_n'  (_biem.py:516-517,742)
+    """
+    d = tr.d
+    j, y, jp, yp = radial(n_end - 1, d, k * rho)
+    h = j + 1j * y
+    hp = jp + 1j * yp
+    gj = alpha * j + beta * k * jp
+    gh = alpha * h + beta * k * hp
+    slc = 1j * k ** (d - 2) * rho ** (d - 1) * j
+    dlc = 1j * k ** (d - 1) * rho ** (d - 1) * jp
+    blc = dlc - 1j * eta * slc
+    return gj, gh, blc
+
+
+def rhs_expansion(tr: Tree, n_end: int, centers, radii, alpha, beta, uin, uin_grad):
+    """f[b, h] = sum_q w_q (-alpha u_in - beta d_n u_in)(c_b + rho_b y_q) conj(Y_h(y_q))  (_biem.py:611-639)."""
+    yq, wq = tr.quadrature(n_end)
+    Y = tr.harmonics(yq, n_end)                         # [H, Q]
+    B = len(radii)
+    f = np.zeros((B, Y.shape[0]), dtype=np.complex128)
+    for b in range(B):
+        x = centers[b][None, :] + radii[b] * yq
+        g = np.zeros(len(wq), dtype=np.complex128)
+        if uin is not None:
+            g = g - alpha[b] * uin(x)
+        if uin_grad is not None:
+            g = g - beta[b] * np.sum(uin_grad(x) * yq, axis=-1)
+        f[b] = np.conj(Y) @ (wq * g)
+    return f
+
+
+def assemble(tr: Tree, n_end: int, k: float, eta: float, centers, radii, alpha, beta, sr_func=None):
+    """Matrix in the reference's scaling, A[b, h, b', h']  (reference _biem.py:745-792)."""
+    B = len(radii)
+    deg = tr.degrees(n_end)
+    H = len(deg)
+    tabs = [ball_tables(tr, n_end, k, eta, radii[b], alpha[b], beta[b]) for b in range(B)]
+    A = np.zeros((B, H, B, H), dtype=np.complex128)
+    for b in range(B):
+        gj, gh, _ = tabs[b]
+        for bp in range(B):
+            blc = tabs[bp][2][deg]                      # column factor blc_{n'}(rho_{b'})
+            if b == bp:
+                A[b, :, bp, :] = np.diag(gh[deg] * blc)
+            else:
+                t = centers[b] - centers[bp]            # argument order of _biem.py:694-699
+                SR = (sr_func or translation_SR)(tr, n_end, k, t)
+                # rows = test index (n p), columns = unknown (n' p')   (_biem.py:769)
+                A[b, :, bp, :] = SR.T * gj[deg][:, None] * blc[None, :]
+    return A, tabs
+
+
+def solve_biem(
+    name: str, *, centers, radii, k: float, n_end: int, eta: float = 1.0, alpha=1.0, beta=0.0,
+    uin=None, uin_grad=None, kind: str = "outer", force_matrix: bool = False, sr_func=None,
+) -> OracleResult:
+    """Restatement of reference ``biem()`` for one (k, eta) instance (no batch dims)."""
+    tr = tree(name)
+    centers = np.asarray(centers, dtype=np.float64).reshape(-1, tr.d)
+    radii = np.asarray(radii, dtype=np.float64).reshape(-1)
+    B = len(radii)
+    alpha = np.broadcast_to(np.asarray(alpha, dtype=np.complex128), (B,))
+    beta = np.broadcast_to(np.asarray(beta, dtype=np.complex128), (B,))
+    if uin is None and uin_grad is None:
+        f = None
+    else:
+        if not np.all(alpha == 0) and uin is None:
+            raise ValueError("alpha is not zero, but uin is None.")
+        if not np.all(beta == 0) and uin_grad is None:
+            raise ValueError("beta is not zero, but uin_grad is None.")
+        f = rhs_expansion(tr, n_end, centers, radii, alpha, beta, uin, uin_grad)
+    deg = tr.degrees(n_end)
+    use_matrix = (f is None) or B > 1 or force_matrix           # _biem.py:643-645
+    if not use_matrix:
+        gj, gh, blc = ball_tables(tr, n_end, k, eta, radii[0], alpha[0], beta[0])
+        dens = f / (blc[deg] * gh[deg])[None, :]                 # _biem.py:673-690
+        return OracleResult(tr, n_end, k, eta, centers, radii, dens, dens * blc[deg][None, :], None, f, kind)
+    A, tabs = assemble(tr, n_end, k, eta, centers, radii, alpha, beta, sr_func)
+    H = len(deg)
+    dens = coef = None
+    if f is not None:
+        dens = np.linalg.solve(A.reshape(B * H, B * H), f.reshape(B * H)).reshape(B, H)   # _biem.py:797
+        coef = np.stack([dens[b] * tabs[b][2][deg] for b in range(B)])
+    return OracleResult(tr, n_end, k, eta, centers, radii, dens, coef, A, f, kind)
+
+
+def uscat(res: OracleResult, x, far_field: bool = False, per_ball: bool = False) -> np.ndarray:
+    """Restatement of reference ``biem_u`` (_biem.py:822-977); x[..., d] -> u[...](, B)."""
+    if res.density is None:
+        raise ValueError("The BIEMResult does not have density.")
+    tr, n_end, k, eta = res.tree, res.n_end, res.k, res.eta
+    d = tr.d
+    x = np.asarray(x, dtype=np.float64)
+    shp = x.shape[:-1]
+    xs = x.reshape(-1, d)
+    deg = tr.degrees(n_end)
+    B = len(res.radii)
+    out = np.zeros((xs.shape[0], B), dtype=np.complex128)
+    bad = np.zeros(xs.shape[0], dtype=bool)
+    for b in range(B):
+        rel = xs - res.centers[b][None, :]
+        r = np.linalg.norm(rel, axis=-1)
+        rs = np.where(r > 0, r, 1.0)
+        Y = tr.harmonics(rel / rs[:, None], n_end)        # [H, P]
+        # blc from the stored (k, eta, rho) -- density * SD_coef * Y  (_biem.py:896-917, 961)
+        j, _, jp, _ = radial(n_end - 1, d, k * res.radii[b])
+        blc = 1j * k ** (d - 1) * res.radii[b] ** (d - 1) * jp - 1j * eta * (1j * k ** (d - 2) * res.radii[b] ** (d - 1) * j)
+        c = res.density[b] * blc[deg]
+        if far_field:
+            # (-i)^n e^{-i k x.c_b} / (i k)^{(d-1)/2}, no radial factor  (_biem.py:930-959)
+            fac = np.exp(-1j * k * (xs @ res.centers[b])) / (1j * k) ** ((d - 1) / 2.0)
+            out[:, b] = ((c * (-1j) ** deg) @ Y) * fac
+        else:
+            hn = np.empty((n_end, xs.shape[0]), dtype=np.complex128)
+            for p, rp in enumerate(rs):
+                jj, yy, _, _ = radial(n_end - 1, d, k * rp)
+                hn[:, p] = jj + 1j * yy
+            out[:, b] = np.sum(c[:, None] * hn[deg, :] * Y, axis=0)
+            if res.kind == "outer":
+                bad |= r < res.radii[b]
+            elif res.kind == "inner":
+                bad |= r > res.radii[b]
+            else:
+                raise ValueError(f"Invalid kind: {res.kind}")
+    if not far_field:
+        out[bad, :] = np.nan
+    if per_ball:
+        return out.reshape(shp + (B,))
+    return out.sum(axis=-1).reshape(shp)
+
+
+# --------------------------------------------------------------------------------------
+# Geometry helper used by the golden-generating driver  (reference cli.py:170-185)
+# --------------------------------------------------------------------------------------
+
+
+def grid_centers(half: int, d: int) -> np.ndarray:
+    if half == 0:
+        c = np.zeros((2, d))
+        c[0, 1] = 2.0
+        c[1, 1] = -2.0
+        return c
+    ax = np.arange(-half, half) * 4.0 + 2.0
+    x0, x1 = np.meshgrid(ax, ax, indexing="ij")
+    cols = [x0.ravel(), x1.ravel()] + [np.zeros(x0.size)] * (d - 2)
+    return np.stack(cols, axis=-1)
