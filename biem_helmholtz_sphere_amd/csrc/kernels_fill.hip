@@ -1,0 +1,336 @@
+// kernels_fill.hip -- special-function tables, matrix fill, RHS projection, density scaling (gfx950).
+//
+// Replaces the span _biem.py:627-639 (RHS) and _biem.py:694-792 (matrix) of the reference, which there is
+// ~40 array-API ops and 3-5 full-size temporaries; here every matrix element is written exactly once.
+#include "common.hpp"
+
+namespace biem {
+
+constexpr int kMaxRad = 320;   // max table order handled per thread-local/LDS radial array
+
+// ---------------------------------------------------------------------------------------------
+// test entry: radial functions at arbitrary arguments
+// ---------------------------------------------------------------------------------------------
+__global__ void k_radial(int d, int nmax, int count, const double* __restrict__ x, double* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double* J = out + (size_t)i * 2 * (nmax + 1);
+  double* Y = J + (nmax + 1);
+  if (d == 4) {
+    // needs one more order: compute integer orders 0..nmax+1 in place with a shifted write
+    double xi = x[i];
+    // order nmax+1 does not fit the output slot: run the recurrence with the last slot as scratch
+    // (output layout leaves no spare element) -> compute J/Y of integer order via local arrays
+    double lj[kMaxRad + 2], ly[kMaxRad + 2];
+    bessel_jy_int(nmax + 1, xi, lj, ly);
+    double f = kSqrtHalfPi / xi;
+    for (int n = 0; n <= nmax; ++n) { J[n] = lj[n + 1] * f; Y[n] = ly[n + 1] * f; }
+  } else {
+    radial_d(d, nmax, x[i], J, Y);
+  }
+}
+
+int launch_radial(int d, int nmax, int count, const double* d_x, double* d_out, hipStream_t st) {
+  if (nmax < 0 || nmax > kMaxRad || (d != 2 && d != 3 && d != 4)) { set_error("biem_radial: bad d/nmax"); return BIEM_ERR_ARG; }
+  if (count <= 0) return BIEM_OK;
+  hipLaunchKernelGGL(k_radial, dim3((count + 63) / 64), dim3(64), 0, st, d, nmax, count, d_x, d_out);
+  BIEM_LAUNCHCHK();
+  return BIEM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// test entry + building block: all harmonics of degree < n_end at given directions
+// ---------------------------------------------------------------------------------------------
+__global__ void k_harmonics(int tree, int d, int H, const int* __restrict__ labels, int count,
+                            const double* __restrict__ u, cplx* __restrict__ Y) {
+  int p = blockIdx.x;
+  if (p >= count) return;
+  double v[4];
+  for (int i = 0; i < d; ++i) v[i] = u[(size_t)p * d + i];
+  Dir dir = make_dir(tree, v);
+  for (int h = threadIdx.x; h < H; h += blockDim.x) {
+    double re, im;
+    harmonic_single(tree, labels[3 * h], labels[3 * h + 1], labels[3 * h + 2], dir, &re, &im);
+    Y[(size_t)p * H + h] = make_double2(re, im);
+  }
+}
+
+int launch_harmonics(const biem_plan* p, int count, const double* d_u, double* d_Y, hipStream_t st) {
+  if (count <= 0) return BIEM_OK;
+  hipLaunchKernelGGL(k_harmonics, dim3(count), dim3(128), 0, st, p->tree, p->d, p->H, p->d_labels, count, d_u, (cplx*)d_Y);
+  BIEM_LAUNCHCHK();
+  return BIEM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K0a: per-ball tables  gj = alpha j + beta k j',  gh = alpha h + beta k h',  blc = dlc - i eta slc
+//   (ush.harmonics_regular_singular_component x4 + potential_coef S/D, _biem.py:723-789)
+// one thread per (system, ball); outputs tab[s][b][3][n_end] complex.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_ball_tables(int d, int n_end, int nb, int B, const double* __restrict__ k, const double* __restrict__ eta,
+                              const double* __restrict__ radii, int geom_batched, const cplx* __restrict__ alpha,
+                              const cplx* __restrict__ beta, int ab_batched, cplx* __restrict__ tab) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb * B) return;
+  int s = i / B, b = i % B;
+  double kk = k[s], et = eta[s];
+  double rho = radii[(geom_batched ? (size_t)s * B : 0) + b];
+  cplx al = alpha[(ab_batched ? (size_t)s * B : 0) + b];
+  cplx be = beta[(ab_batched ? (size_t)s * B : 0) + b];
+  double J[kMaxRad + 3], Y[kMaxRad + 3];
+  double x = kk * rho;
+  radial_d(d, n_end, x, J, Y);   // orders 0..n_end (one extra for the derivative)
+  cplx* out = tab + (size_t)i * 3 * n_end;
+  double rp = 1.0;               // rho^{d-1}
+  for (int q = 0; q < d - 1; ++q) rp *= rho;
+  double kd2 = 1.0;              // k^{d-2}
+  for (int q = 0; q < d - 2; ++q) kd2 *= kk;
+  for (int n = 0; n < n_end; ++n) {
+    double j = J[n], y = Y[n];
+    double jp = (double)n / x * j - J[n + 1];
+    double yp = (double)n / x * y - Y[n + 1];
+    // gj = alpha j + beta k j'
+    cplx gj = make_double2(al.x * j + be.x * kk * jp, al.y * j + be.y * kk * jp);
+    // gh = alpha (j + i y) + beta k (j' + i y')
+    cplx h = make_double2(j, y), hp = make_double2(kk * jp, kk * yp);
+    cplx gh = cadd(cmul(al, h), cmul(be, hp));
+    // blc = i k^{d-1} rho^{d-1} j' - i eta * i k^{d-2} rho^{d-1} j = k^{d-2} rho^{d-1} (eta j + i k j')
+    cplx blc = make_double2(kd2 * rp * et * j, kd2 * rp * kk * jp);
+    out[n] = gj;
+    out[n_end + n] = gh;
+    out[2 * n_end + n] = blc;
+  }
+}
+
+int launch_ball_tables(const biem_plan* p, int nb, int B, const double* d_k, const double* d_eta, const double* d_radii,
+                       int geom_batched, const double* d_alpha, const double* d_beta, int ab_batched, double* d_tab, hipStream_t st) {
+  if (p->n_end > kMaxRad) { set_error("n_end=%d exceeds the built table size %d", p->n_end, kMaxRad); return BIEM_ERR_UNSUPPORTED; }
+  int total = nb * B;
+  if (total <= 0) return BIEM_OK;
+  ProfScope ps(PK_TABLES, st);
+  hipLaunchKernelGGL(k_ball_tables, dim3((total + 63) / 64), dim3(64), 0, st, p->d, p->n_end, nb, B, d_k, d_eta, d_radii,
+                     geom_batched, (const cplx*)d_alpha, (const cplx*)d_beta, ab_batched, (cplx*)d_tab);
+  BIEM_LAUNCHCHK();
+  return BIEM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K0b: per-pair translation tables  T[s][b][b'][l] = C_d h_{n''}(k |t|) Y_l(t^),  t = c_b - c_b'
+//   (argument order of _biem.py:694-699), l over labels of degree < 2 n_end - 1.
+// One wave per (system, ordered pair): lane 0 runs the radial recurrences into LDS, then all lanes
+// evaluate harmonics.  Diagonal pairs are skipped (the reference evaluates them at t = 0 and masks
+// the inf/nan afterwards, _biem.py:745-746).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int H2, double Cd, const int* __restrict__ labels2,
+                                                     const int* __restrict__ deg2, int B, const double* __restrict__ k,
+                                                     const double* __restrict__ centers, int geom_batched, cplx* __restrict__ T) {
+  __shared__ double sJ[kMaxRad * 2 + 6];
+  __shared__ double sY[kMaxRad * 2 + 6];
+  int pair = blockIdx.x, s = blockIdx.y;
+  int b = pair / B, bp = pair % B;
+  if (b == bp) return;
+  const double* cb = centers + ((geom_batched ? (size_t)s * B : 0) + b) * d;
+  const double* cp = centers + ((geom_batched ? (size_t)s * B : 0) + bp) * d;
+  double t[4];
+  double r2 = 0.0;
+  for (int i = 0; i < d; ++i) { t[i] = cb[i] - cp[i]; r2 += t[i] * t[i]; }
+  double r = sqrt(r2);
+  if (threadIdx.x == 0) radial_d(d, n2 - 1, k[s] * r, sJ, sY);
+  __syncthreads();
+  Dir dir = make_dir(tree, t);
+  cplx* out = T + ((size_t)s * B * B + pair) * H2;
+  for (int l = threadIdx.x; l < H2; l += 64) {
+    double re, im;
+    harmonic_single(tree, labels2[3 * l], labels2[3 * l + 1], labels2[3 * l + 2], dir, &re, &im);
+    int n = deg2[l];
+    cplx h = make_double2(Cd * sJ[n], Cd * sY[n]);
+    out[l] = cmul(h, make_double2(re, im));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1-K3: generic fill.  For every ordered pair block (b, b') and every entry (h, h'):
+//   off-diagonal:  A = R_b[n(h)] * Cc_{b'}[n(h')] * sum_p coef[p] T_{bb'}[tidx[p]]        ((S|R)^T, _biem.py:769)
+//   diagonal    :  A = delta_{hh'} * Dg_b[n(h)]
+// with (R, Cc, Dg) = (gj, blc, gh*blc) for the reference scaling (_biem.py:745-789) and (gj, 1/gh, 1) for the
+// equilibrated system the LU factors.  One block per (row chunk, pair, system); the pair's T table sits in LDS;
+// consecutive lanes own consecutive columns h' -> 16-byte coalesced stores, each element written once.
+// ---------------------------------------------------------------------------------------------
+template <int ROWS>
+__global__ void __launch_bounds__(256) k_fill(int H, int H2, int n_end, int B, const int* __restrict__ deg,
+                                               const uint32_t* __restrict__ ptr, const double* __restrict__ coef,
+                                               const int32_t* __restrict__ tidx, const cplx* __restrict__ T,
+                                               const cplx* __restrict__ tab, int scaling, cplx* __restrict__ A, long long lda,
+                                               long long sys_stride) {
+  extern __shared__ cplx sT[];   // [H2] + column factors [H]
+  cplx* sC = sT + H2;
+  int pair = blockIdx.y, s = blockIdx.z;
+  int b = pair / B, bp = pair % B;
+  int h0 = blockIdx.x * ROWS;
+  cplx* Ab = A + (size_t)s * sys_stride + ((size_t)b * H) * lda + (size_t)bp * H;
+  const cplx* tb = tab + ((size_t)s * B + b) * 3 * n_end;
+  const cplx* tbp = tab + ((size_t)s * B + bp) * 3 * n_end;
+  if (b == bp) {
+    for (int r = 0; r < ROWS; ++r) {
+      int h = h0 + r;
+      if (h >= H) break;
+      int n = deg[h];
+      cplx dg = scaling == BIEM_FILL_REFERENCE ? cmul(tb[n_end + n], tb[2 * n_end + n]) : make_double2(1.0, 0.0);
+      for (int hp = threadIdx.x; hp < H; hp += 256) Ab[(size_t)h * lda + hp] = (hp == h) ? dg : make_double2(0.0, 0.0);
+    }
+    return;
+  }
+  const cplx* Tp = T + ((size_t)s * B * B + pair) * H2;
+  for (int l = threadIdx.x; l < H2; l += 256) sT[l] = Tp[l];
+  for (int hp = threadIdx.x; hp < H; hp += 256) {
+    int n = deg[hp];
+    sC[hp] = scaling == BIEM_FILL_REFERENCE ? tbp[2 * n_end + n] : crecip(tbp[n_end + n]);
+  }
+  __syncthreads();
+  for (int r = 0; r < ROWS; ++r) {
+    int h = h0 + r;
+    if (h >= H) break;
+    cplx rowf = tb[deg[h]];   // gj
+    const uint32_t* pr = ptr + (size_t)h * H;
+    for (int hp = threadIdx.x; hp < H; hp += 256) {
+      uint32_t p0 = pr[hp], p1 = pr[hp + 1];
+      double ar = 0.0, ai = 0.0;
+      for (uint32_t q = p0; q < p1; ++q) {
+        double c = coef[q];
+        cplx t = sT[tidx[q]];
+        ar = fma(c, t.x, ar);
+        ai = fma(c, t.y, ai);
+      }
+      cplx v = cmul(cmul(make_double2(ar, ai), rowf), sC[hp]);
+      Ab[(size_t)h * lda + hp] = v;
+    }
+  }
+}
+
+// identity padding: rows/cols N..n_pad-1
+__global__ void k_fill_pad(int N, int n_pad, cplx* __restrict__ A, long long lda, long long sys_stride) {
+  int s = blockIdx.y;
+  cplx* As = A + (size_t)s * sys_stride;
+  int npadrows = n_pad - N;
+  // region 1: rows [N, n_pad) x cols [0, n_pad);  region 2: rows [0, N) x cols [N, n_pad)
+  long long total1 = (long long)npadrows * n_pad, total2 = (long long)N * npadrows;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total1 + total2; i += (long long)gridDim.x * blockDim.x) {
+    int r, c;
+    if (i < total1) { r = N + (int)(i / n_pad); c = (int)(i % n_pad); }
+    else { long long q = i - total1; r = (int)(q / npadrows); c = N + (int)(q % npadrows); }
+    As[(size_t)r * lda + c] = (r == c) ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
+  }
+}
+
+size_t fill_workspace_bytes(const biem_plan* p, int nb, int B) { return (size_t)nb * B * B * p->H2 * sizeof(cplx); }
+
+int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const double* d_centers, int geom_batched,
+                const double* d_tab, int scaling, double* d_A, long long lda, long long sys_stride, int n_pad,
+                void* d_work, size_t work_bytes, hipStream_t st) {
+  const int H = p->H, N = B * H;
+  if (nb <= 0 || B <= 0) return BIEM_OK;
+  if (lda < (n_pad > N ? n_pad : N) || n_pad < N) { set_error("biem_fill: lda/n_pad too small"); return BIEM_ERR_ARG; }
+  if (work_bytes < fill_workspace_bytes(p, nb, B)) { set_error("biem_fill: workspace too small"); return BIEM_ERR_ARG; }
+  if (2 * p->n_end > kMaxRad) { set_error("n_end=%d exceeds the built table size", p->n_end); return BIEM_ERR_UNSUPPORTED; }
+  if (scaling != BIEM_FILL_REFERENCE && scaling != BIEM_FILL_EQUILIBRATED) { set_error("biem_fill: bad scaling"); return BIEM_ERR_ARG; }
+  cplx* T = (cplx*)d_work;
+  ProfScope ps(PK_FILL, st, 16.0 * (double)nb * N * (double)N);
+  if (B > 1) {
+    hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2,
+                       p->d_deg2, B, d_k, d_centers, geom_batched, T);
+    BIEM_LAUNCHCHK();
+  }
+  constexpr int ROWS = 8;
+  size_t shm = (size_t)(p->H2 + H) * sizeof(cplx);
+  if (shm > 160 * 1024) { set_error("biem_fill: translation table does not fit LDS (H2=%d)", p->H2); return BIEM_ERR_UNSUPPORTED; }
+  if (shm > 64 * 1024) BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_fill<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  hipLaunchKernelGGL(k_fill<ROWS>, dim3((H + ROWS - 1) / ROWS, B * B, nb), dim3(256), shm, st, H, p->H2, p->n_end, B, p->d_deg,
+                     p->d_ptr, p->d_coef, p->d_tidx, T, (const cplx*)d_tab, scaling, (cplx*)d_A, lda, sys_stride);
+  BIEM_LAUNCHCHK();
+  if (n_pad > N) {
+    hipLaunchKernelGGL(k_fill_pad, dim3(64, nb), dim3(256), 0, st, N, n_pad, (cplx*)d_A, lda, sys_stride);
+    BIEM_LAUNCHCHK();
+  }
+  return BIEM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RHS projection  f[row][h] = sum_q g[row][q] W[q][h]   (ush.expand, _biem.py:627-639)
+// block = RT rows x 256 columns; g rows staged in LDS, W streamed coalesced along h.
+// ---------------------------------------------------------------------------------------------
+template <int RT>
+__global__ void __launch_bounds__(256) k_rhs_project(int H, int Q, int rows, int B, const cplx* __restrict__ g,
+                                                      const cplx* __restrict__ W, cplx* __restrict__ f, long long sys_stride,
+                                                      long long elem_stride) {
+  extern __shared__ cplx sg[];   // [RT][QC]
+  constexpr int QC = 256;
+  int row0 = blockIdx.y * RT;
+  int h = blockIdx.x * 256 + threadIdx.x;
+  cplx acc[RT];
+  for (int r = 0; r < RT; ++r) acc[r] = make_double2(0.0, 0.0);
+  for (int q0 = 0; q0 < Q; q0 += QC) {
+    int qn = min(QC, Q - q0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < RT * QC; i += 256) {
+      int r = i / QC, q = i % QC;
+      sg[i] = (row0 + r < rows && q < qn) ? g[(size_t)(row0 + r) * Q + q0 + q] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    if (h < H) {
+      for (int q = 0; q < qn; ++q) {
+        cplx w = W[(size_t)(q0 + q) * H + h];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r] = cfma(sg[r * QC + q], w, acc[r]);
+      }
+    }
+  }
+  if (h < H) {
+    for (int r = 0; r < RT; ++r) {
+      int row = row0 + r;
+      if (row >= rows) break;
+      long long s = row / B, b = row % B;
+      f[(size_t)s * sys_stride + ((size_t)b * H + h) * elem_stride] = acc[r];
+    }
+  }
+}
+
+int launch_rhs_project(const biem_plan* p, int nb, int B, const double* d_g, double* d_f, long long sys_stride,
+                       long long elem_stride, hipStream_t st) {
+  int rows = nb * B;
+  if (rows <= 0) return BIEM_OK;
+  constexpr int RT = 8;
+  size_t shm = (size_t)RT * 256 * sizeof(cplx);
+  ProfScope ps(PK_RHS, st, 8.0 * (double)rows * p->Q * p->H);
+  hipLaunchKernelGGL(k_rhs_project<RT>, dim3((p->H + 255) / 256, (rows + RT - 1) / RT), dim3(256), shm, st, p->H, p->Q, rows, B,
+                     (const cplx*)d_g, (const cplx*)p->d_W, (cplx*)d_f, sys_stride, elem_stride);
+  BIEM_LAUNCHCHK();
+  return BIEM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// density = x / (gh * blc)   (reference scaling of the unknown; single-ball shortcut _biem.py:673-690 with x = f)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_density(int H, int n_end, int B, long long total, const int* __restrict__ deg, const cplx* __restrict__ x,
+                          long long sys_stride, long long elem_stride, const cplx* __restrict__ tab, cplx* __restrict__ dens) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int h = (int)(i % H);
+  long long sb = i / H;
+  long long s = sb / B, b = sb % B;
+  int n = deg[h];
+  const cplx* t = tab + (size_t)sb * 3 * n_end;
+  cplx v = x[(size_t)s * sys_stride + ((size_t)b * H + h) * elem_stride];
+  dens[i] = cmul(v, crecip(cmul(t[n_end + n], t[2 * n_end + n])));
+}
+
+int launch_density(const biem_plan* p, int nb, int B, const double* d_x, long long sys_stride, long long elem_stride,
+                   const double* d_tab, double* d_density, hipStream_t st) {
+  long long total = (long long)nb * B * p->H;
+  if (total <= 0) return BIEM_OK;
+  hipLaunchKernelGGL(k_density, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p->H, p->n_end, B, total, p->d_deg,
+                     (const cplx*)d_x, sys_stride, elem_stride, (const cplx*)d_tab, (cplx*)d_density);
+  BIEM_LAUNCHCHK();
+  return BIEM_OK;
+}
+
+}  // namespace biem

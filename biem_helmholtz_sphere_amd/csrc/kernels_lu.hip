@@ -1,0 +1,422 @@
+// kernels_lu.hip -- K4/K5: batched dense complex LU with partial pivoting + triangular solves on gfx950.
+//
+// Replaces batch_tensorsolve.btensorsolve -> linalg.solve (LAPACK zgesv) at reference _biem.py:797.
+//
+// Layout: every system is the augmented row-major matrix [M | F] with n_pad rows, n_cols = n_pad + nrhs columns and
+// leading dimension lda (complex128 elements).  Right-looking blocked LU, panel width NB:
+//   panel_load   M[j:, j:j+NB] -> P (column-major workspace, so the pivot search and the rank-1 updates are coalesced)
+//   panel_factor unblocked LU with partial pivoting on P (one workgroup per system)
+//   panel_store  P -> M (L21 stays in P: it is the A operand of the trailing zgemm in exactly the [k][i] order
+//                the f64 MFMA A-fragment wants, so it is staged to LDS without a transpose)
+//   swap         row interchanges on the columns outside the panel (coalesced: rows are contiguous)
+//   trsm         U12 = L11^{-1} M[j:j+NB, j+NB:]   (includes the right-hand-side columns: forward elimination rides along)
+//   gemm         M[j+NB:, j+NB:] -= L21 * U12      zgemm on v_mfma_f64_16x16x4_f64 (4 real MFMAs per complex tile-step)
+// then a blocked back substitution with U.  All kernels are batched over systems (blockIdx.z / .y).
+#include "common.hpp"
+
+namespace biem {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int NB = 64;    // panel width
+constexpr int BS = 64;    // back-substitution block
+
+int lu_npad(int N) { return ((N + NB - 1) / NB) * NB; }
+
+static inline long long ldp_of(int n_pad) { return (long long)n_pad; }
+
+size_t lu_workspace_bytes(int nb, int n_pad, int nrhs) {
+  (void)nrhs;
+  return (size_t)nb * NB * (size_t)ldp_of(n_pad) * sizeof(cplx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// panel load / store (transposing copies through LDS)
+// ---------------------------------------------------------------------------------------------
+constexpr int TR = 32;   // rows per transpose tile
+__global__ void __launch_bounds__(256) k_panel_load(const cplx* __restrict__ A, long long lda, long long sys_stride,
+                                                     cplx* __restrict__ Pw, long long ldp, long long p_stride, int n_pad, int j) {
+  __shared__ cplx tile[TR][NB + 1];
+  const int s = blockIdx.y, i0 = j + blockIdx.x * TR;
+  const cplx* As = A + (size_t)s * sys_stride;
+  cplx* Ps = Pw + (size_t)s * p_stride;
+  for (int idx = threadIdx.x; idx < TR * NB; idx += 256) {
+    int r = idx / NB, c = idx % NB, gi = i0 + r;
+    if (gi < n_pad) tile[r][c] = As[(size_t)gi * lda + j + c];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < TR * NB; idx += 256) {
+    int c = idx / TR, r = idx % TR, gi = i0 + r;
+    if (gi < n_pad) Ps[(size_t)c * ldp + gi] = tile[r][c];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_panel_store(cplx* __restrict__ A, long long lda, long long sys_stride,
+                                                      const cplx* __restrict__ Pw, long long ldp, long long p_stride, int n_pad, int j) {
+  __shared__ cplx tile[TR][NB + 1];
+  const int s = blockIdx.y, i0 = j + blockIdx.x * TR;
+  cplx* As = A + (size_t)s * sys_stride;
+  const cplx* Ps = Pw + (size_t)s * p_stride;
+  for (int idx = threadIdx.x; idx < TR * NB; idx += 256) {
+    int c = idx / TR, r = idx % TR, gi = i0 + r;
+    if (gi < n_pad) tile[r][c] = Ps[(size_t)c * ldp + gi];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < TR * NB; idx += 256) {
+    int r = idx / NB, c = idx % NB, gi = i0 + r;
+    if (gi < n_pad) As[(size_t)gi * lda + j + c] = tile[r][c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// panel factorisation: unblocked right-looking LU with partial pivoting on the column-major panel.
+// Pivot = max |re| + |im| (LAPACK izamax's cabs1), ties -> smallest row.  One 1024-thread workgroup per system.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_panel_factor(cplx* __restrict__ Pw, long long ldp, long long p_stride, int n_pad, int j,
+                                                        int* __restrict__ ipiv, int* __restrict__ info) {
+  __shared__ double sval[16];
+  __shared__ int sidx[16];
+  __shared__ cplx sU[NB];
+  __shared__ int sPiv;
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  cplx* Ps = Pw + (size_t)s * p_stride;
+  for (int c = 0; c < NB; ++c) {
+    cplx* col = Ps + (size_t)c * ldp;
+    const int r0 = j + c;
+    double best = -1.0;
+    int bi = 0x7fffffff;
+    for (int i = r0 + tid; i < n_pad; i += 1024) {
+      cplx v = col[i];
+      double a = fabs(v.x) + fabs(v.y);
+      if (a > best) { best = a; bi = i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      double ob = __shfl_down(best, o, 64);
+      int oi = __shfl_down(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { sval[wave] = best; sidx[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      double b = sval[0]; int ix = sidx[0];
+      for (int w = 1; w < 16; ++w) if (sval[w] > b || (sval[w] == b && sidx[w] < ix)) { b = sval[w]; ix = sidx[w]; }
+      if (ix == 0x7fffffff) ix = r0;   // all-NaN column: keep the diagonal
+      sPiv = ix;
+      ipiv[(size_t)s * n_pad + r0] = ix;
+    }
+    __syncthreads();
+    const int p = sPiv;
+    if (tid < NB) {
+      cplx a = Ps[(size_t)tid * ldp + r0];
+      if (p != r0) {
+        cplx b = Ps[(size_t)tid * ldp + p];
+        Ps[(size_t)tid * ldp + p] = a;
+        Ps[(size_t)tid * ldp + r0] = b;
+        a = b;
+      }
+      sU[tid] = a;   // row r0 of the panel after the interchange
+    }
+    __syncthreads();
+    const cplx piv = sU[c];
+    if (piv.x == 0.0 && piv.y == 0.0) {
+      if (tid == 0 && info[s] == 0) info[s] = r0 + 1;
+      continue;   // uniform: exactly singular column, nothing to eliminate
+    }
+    const cplx rinv = crecip(piv);
+    for (int i = r0 + 1 + tid; i < n_pad; i += 1024) {
+      cplx l = cmul(col[i], rinv);
+      col[i] = l;
+      for (int cc = c + 1; cc < NB; ++cc) {
+        cplx* q = Ps + (size_t)cc * ldp + i;
+        *q = cfnma(l, sU[cc], *q);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// row interchanges outside the panel: thread per column, all NB swaps in order.
+// columns: left part [0, j) when `left`, right part [j+NB, n_cols).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_swap(cplx* __restrict__ A, long long lda, long long sys_stride, int n_pad, int n_cols,
+                                               int j, const int* __restrict__ ipiv, int left) {
+  __shared__ int sp[NB];
+  const int s = blockIdx.y;
+  if (threadIdx.x < NB) sp[threadIdx.x] = ipiv[(size_t)s * n_pad + j + threadIdx.x];
+  __syncthreads();
+  int t = blockIdx.x * 256 + threadIdx.x;
+  int col;
+  if (left) { col = t < j ? t : t + NB; } else { col = t + j + NB; }
+  if (col >= n_cols) return;
+  cplx* As = A + (size_t)s * sys_stride + col;
+  for (int c = 0; c < NB; ++c) {
+    int p = sp[c];
+    if (p != j + c) {
+      cplx a = As[(size_t)(j + c) * lda], b = As[(size_t)p * lda];
+      As[(size_t)(j + c) * lda] = b;
+      As[(size_t)p * lda] = a;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// U12 = L11^{-1} A12 on a [NB x TC] column tile held in LDS; L11 (unit lower) is read from the panel workspace.
+// ---------------------------------------------------------------------------------------------
+constexpr int TC = 32;
+__global__ void __launch_bounds__(256) k_trsm(cplx* __restrict__ A, long long lda, long long sys_stride, const cplx* __restrict__ Pw,
+                                               long long ldp, long long p_stride, int n_cols, int j) {
+  __shared__ cplx tile[NB][TC + 1];
+  const int s = blockIdx.y, c0 = j + NB + blockIdx.x * TC;
+  cplx* As = A + (size_t)s * sys_stride;
+  const cplx* Ps = Pw + (size_t)s * p_stride;
+  const int n = threadIdx.x % TC, g = threadIdx.x / TC;   // 8 row groups
+  const bool ok = c0 + n < n_cols;
+  for (int r = g; r < NB; r += 8) tile[r][n] = ok ? As[(size_t)(j + r) * lda + c0 + n] : make_double2(0.0, 0.0);
+  __syncthreads();
+  for (int r = 0; r < NB - 1; ++r) {
+    cplx u = tile[r][n];
+    for (int i = r + 1 + g; i < NB; i += 8) {
+      cplx l = Ps[(size_t)r * ldp + j + i];
+      tile[i][n] = cfnma(l, u, tile[i][n]);
+    }
+    __syncthreads();
+  }
+  if (ok) for (int r = g; r < NB; r += 8) As[(size_t)(j + r) * lda + c0 + n] = tile[r][n];
+}
+
+// ---------------------------------------------------------------------------------------------
+// trailing update  C[i][n] -= sum_c L21[i][c] U12[c][n]   --  zgemm on v_mfma_f64_16x16x4_f64.
+//   A operand = L21 from the column-major panel workspace P[c][i]  -> LDS sA[k][i]   (no transpose)
+//   B operand = U12 rows of M, row-major [c][n]                      -> LDS sB[k][n]   (no transpose)
+//   f64 MFMA fragments: lane l holds A[i = l&15][k = l>>4], B[k = l>>4][n = l&15]; C/D: col = l&15, row = (l>>4) + 4*reg.
+//   complex product = 4 real MFMAs: Cr += Ar*Br; Cr += (-Ai)*Bi; Ci += Ar*Bi; Ci += Ai*Br.
+// Workgroup tile 128 x 128, 8 waves as 4(M) x 2(N), wave tile 32 x 64 = 2 x 4 MFMA tiles (16 accumulator tiles of 4 f64:
+// 128 VGPRs), K staged in chunks of 8 through double-buffered LDS (64 KiB), one barrier per chunk.
+// LDS reads are ds_read_b128 of 16 consecutive complex per k-row: conflict-free (MI355X_MICROARCH.md, LDS table).
+// ---------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, KC = 8;
+
+__global__ void __launch_bounds__(512) k_gemm(cplx* __restrict__ A, long long lda, long long sys_stride, const cplx* __restrict__ Pw,
+                                               long long ldp, long long p_stride, int n_pad, int n_cols, int j) {
+  __shared__ cplx sA[2][KC][BM];
+  __shared__ cplx sB[2][KC][BN];
+  const int s = blockIdx.z;
+  const int row0 = j + NB + blockIdx.y * BM;
+  const int col0 = j + NB + blockIdx.x * BN;
+  cplx* As = A + (size_t)s * sys_stride;
+  const cplx* Ps = Pw + (size_t)s * p_stride;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  v4d accR[2][4], accI[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { accR[a][b] = (v4d){0, 0, 0, 0}; accI[a][b] = (v4d){0, 0, 0, 0}; }
+
+  // staging map: element id = tid + 512 r (r = 0, 1): k-row = id >> 7, position = id & 127
+  const int sk0 = tid >> 7, si = tid & 127;
+  const bool rowok = row0 + si < n_pad, colok = col0 + si < n_cols;
+  cplx ra[2], rb[2];
+  const cplx zero = make_double2(0.0, 0.0);
+  auto gload = [&](int kc) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      int kk = kc + sk0 + 4 * r;
+      ra[r] = rowok ? Ps[(size_t)kk * ldp + row0 + si] : zero;
+      rb[r] = colok ? As[(size_t)(j + kk) * lda + col0 + si] : zero;
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      sA[buf][sk0 + 4 * r][si] = ra[r];
+      sB[buf][sk0 + 4 * r][si] = rb[r];
+    }
+  };
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kc = 0; kc < NB; kc += KC) {
+    const int buf = (kc / KC) & 1;
+    const bool more = kc + KC < NB;
+    if (more) gload(kc + KC);
+#pragma unroll
+    for (int k4 = 0; k4 < KC / 4; ++k4) {
+      const int kk = k4 * 4 + l4;
+      cplx a[2], b[4];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) a[tm] = sA[buf][kk][wm * 32 + tm * 16 + l15];
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) b[tn] = sB[buf][kk][wn * 64 + tn * 16 + l15];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        const double nai = -a[tm].y;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+          accR[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm].x, b[tn].x, accR[tm][tn], 0, 0, 0);
+          accI[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm].x, b[tn].y, accI[tm][tn], 0, 0, 0);
+          accR[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, b[tn].y, accR[tm][tn], 0, 0, 0);
+          accI[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm].y, b[tn].x, accI[tm][tn], 0, 0, 0);
+        }
+      }
+    }
+    if (more) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  // epilogue: C -= acc
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int col = col0 + wn * 64 + tn * 16 + l15;
+      if (col >= n_cols) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + wm * 32 + tm * 16 + l4 + 4 * r;
+        if (row < n_pad) {
+          cplx* q = As + (size_t)row * lda + col;
+          cplx c = *q;
+          c.x -= accR[tm][tn][r];
+          c.y -= accI[tm][tn][r];
+          *q = c;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// back substitution with U (row-major), block size BS
+// ---------------------------------------------------------------------------------------------
+// diagonal block: x = U[jr:jr+BS, jr:jr+BS]^{-1} y, one 64-thread workgroup per (system, rhs)
+__global__ void __launch_bounds__(64) k_back_diag(cplx* __restrict__ A, long long lda, long long sys_stride, int n_pad, int jr) {
+  __shared__ cplx sx;
+  const int s = blockIdx.x, q = blockIdx.y, r = threadIdx.x;
+  cplx* As = A + (size_t)s * sys_stride;
+  const cplx* Urow = As + (size_t)(jr + r) * lda + jr;
+  cplx y = As[(size_t)(jr + r) * lda + n_pad + q];
+  for (int c = BS - 1; c >= 0; --c) {
+    if (r == c) { y = cmul(y, crecip(Urow[c])); sx = y; }
+    __syncthreads();
+    if (r < c) y = cfnma(Urow[c], sx, y);
+    __syncthreads();
+  }
+  As[(size_t)(jr + r) * lda + n_pad + q] = y;
+}
+
+// rows above: y[i] -= sum_c U[i][jr+c] x[jr+c]; one wave per row
+__global__ void __launch_bounds__(256) k_back_update(cplx* __restrict__ A, long long lda, long long sys_stride, int n_pad, int nrhs, int jr) {
+  const int s = blockIdx.y, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= jr) return;
+  cplx* As = A + (size_t)s * sys_stride;
+  cplx u = As[(size_t)i * lda + jr + lane];
+  for (int q = 0; q < nrhs; ++q) {
+    cplx x = As[(size_t)(jr + lane) * lda + n_pad + q];
+    cplx v = cmul(u, x);
+    double vr = v.x, vi = v.y;
+    for (int o = 32; o > 0; o >>= 1) { vr += __shfl_down(vr, o, 64); vi += __shfl_down(vi, o, 64); }
+    if (lane == 0) {
+      cplx* y = As + (size_t)i * lda + n_pad + q;
+      cplx t = *y;
+      t.x -= vr; t.y -= vi;
+      *y = t;
+    }
+  }
+}
+
+__global__ void k_zero_int(int* p, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
+int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_ipiv,
+                           int* d_info, void* d_work, size_t work_bytes, hipStream_t st) {
+  if (nb <= 0 || n_pad <= 0) return BIEM_OK;
+  if (n_pad % NB) { set_error("biem_lu: n_pad=%d is not a multiple of %d (use biem_lu_npad)", n_pad, NB); return BIEM_ERR_ARG; }
+  if (nrhs < 0 || lda < n_pad + nrhs) { set_error("biem_lu: lda < n_pad + nrhs"); return BIEM_ERR_ARG; }
+  if (work_bytes < lu_workspace_bytes(nb, n_pad, nrhs)) { set_error("biem_lu: workspace too small"); return BIEM_ERR_ARG; }
+  cplx* A = (cplx*)d_A;
+  cplx* Pw = (cplx*)d_work;
+  const long long ldp = ldp_of(n_pad), p_stride = (long long)NB * ldp;
+  const int n_cols = n_pad + nrhs;
+  hipLaunchKernelGGL(k_zero_int, dim3((nb + 63) / 64), dim3(64), 0, st, d_info, nb);
+  for (int j = 0; j < n_pad; j += NB) {
+    const int rows = n_pad - j;
+    {
+      ProfScope ps(PK_PANEL, st, 4.0 * (double)nb * rows * NB * NB);
+      hipLaunchKernelGGL(k_panel_load, dim3((rows + TR - 1) / TR, nb), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, n_pad, j);
+      hipLaunchKernelGGL(k_panel_factor, dim3(nb), dim3(1024), 0, st, Pw, ldp, p_stride, n_pad, j, d_ipiv, d_info);
+      hipLaunchKernelGGL(k_panel_store, dim3((rows + TR - 1) / TR, nb), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, n_pad, j);
+    }
+    const int rcols = n_cols - (j + NB);   // columns right of the panel (>= nrhs)
+    if (rcols > 0) {
+      {
+        ProfScope ps(PK_SWAP, st, 64.0 * (double)nb * NB * rcols);
+        hipLaunchKernelGGL(k_swap, dim3((rcols + 255) / 256, nb), dim3(256), 0, st, A, lda, sys_stride, n_pad, n_cols, j, d_ipiv, 0);
+      }
+      {
+        ProfScope ps(PK_TRSM, st, 4.0 * (double)nb * NB * NB * rcols);
+        hipLaunchKernelGGL(k_trsm, dim3((rcols + TC - 1) / TC, nb), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, n_cols, j);
+      }
+      const int rrows = n_pad - (j + NB);
+      if (rrows > 0) {
+        ProfScope ps(PK_GEMM, st, 8.0 * (double)nb * rrows * (double)rcols * NB);
+        hipLaunchKernelGGL(k_gemm, dim3((rcols + BN - 1) / BN, (rrows + BM - 1) / BM, nb), dim3(512), 0, st, A, lda, sys_stride, Pw,
+                           ldp, p_stride, n_pad, n_cols, j);
+      }
+    }
+  }
+  BIEM_LAUNCHCHK();
+  if (nrhs > 0) {
+    ProfScope ps(PK_BACK, st, 4.0 * (double)nb * n_pad * (double)n_pad * nrhs);
+    for (int jr = n_pad - BS; jr >= 0; jr -= BS) {
+      hipLaunchKernelGGL(k_back_diag, dim3(nb, nrhs), dim3(64), 0, st, A, lda, sys_stride, n_pad, jr);
+      if (jr > 0)
+        hipLaunchKernelGGL(k_back_update, dim3((jr + 3) / 4, nb), dim3(256), 0, st, A, lda, sys_stride, n_pad, nrhs, jr);
+    }
+    BIEM_LAUNCHCHK();
+  }
+  return BIEM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// microbenchmark: issue rate of v_mfma_f64_16x16x4_f64 (confirms the FP64 matrix peak the roofline is priced against)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bench_mfma(int iters, double* sink) {
+  v4d acc[8];
+  for (int i = 0; i < 8; ++i) acc[i] = (v4d){0, 0, 0, 0};
+  double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double sacc = 0.0;
+  for (int i = 0; i < 8; ++i) sacc += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (sacc == 123.456) sink[0] = sacc;
+}
+
+int bench_mfma_f64(int iters, double* tflops, hipStream_t st) {
+  double* sink = nullptr;
+  BIEM_HIPCHK(hipMalloc((void**)&sink, 8));
+  hipEvent_t e0, e1;
+  BIEM_HIPCHK(hipEventCreate(&e0));
+  BIEM_HIPCHK(hipEventCreate(&e1));
+  const int blocks = 256 * 2;   // 2 workgroups of 4 waves per CU -> 2 waves per SIMD
+  hipLaunchKernelGGL(k_bench_mfma, dim3(blocks), dim3(256), 0, st, 16, sink);   // warm-up
+  BIEM_HIPCHK(hipEventRecord(e0, st));
+  hipLaunchKernelGGL(k_bench_mfma, dim3(blocks), dim3(256), 0, st, iters, sink);
+  BIEM_HIPCHK(hipEventRecord(e1, st));
+  BIEM_HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  BIEM_HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  double flops = (double)blocks * 4.0 * (double)iters * 8.0 * (2.0 * 16 * 16 * 4);
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
+  return BIEM_OK;
+}
+
+}  // namespace biem

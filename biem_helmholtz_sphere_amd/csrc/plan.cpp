@@ -1,0 +1,243 @@
+// plan.cpp -- host-side table builder (pure C++; the only HIP calls are the uploads).
+#include "plan.hpp"
+#include "../../include/biem_mi355.h"
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+
+namespace biem {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+// ---- quadrature nodes ---------------------------------------------------------------------
+static void gauss_legendre(int n, std::vector<double>& t, std::vector<double>& w) {
+  t.assign(n, 0.0); w.assign(n, 0.0);
+  for (int i = 0; i < n; ++i) {
+    double x = cos(kPi * (i + 0.75) / (n + 0.5));
+    double pp = 1.0;
+    for (int it = 0; it < 100; ++it) {
+      double p0 = 1.0, p1 = x;
+      for (int k = 2; k <= n; ++k) { double p2 = ((2.0 * k - 1.0) * x * p1 - (k - 1.0) * p0) / k; p0 = p1; p1 = p2; }
+      if (n == 1) { p0 = 1.0; p1 = x; }
+      pp = n * (x * p1 - p0) / (x * x - 1.0);
+      double dx = p1 / pp;
+      x -= dx;
+      if (fabs(dx) < 1e-16) break;
+    }
+    // final derivative at the converged node
+    double p0 = 1.0, p1 = x;
+    for (int k = 2; k <= n; ++k) { double p2 = ((2.0 * k - 1.0) * x * p1 - (k - 1.0) * p0) / k; p0 = p1; p1 = p2; }
+    pp = n * (x * p1 - p0) / (x * x - 1.0);
+    t[n - 1 - i] = x;                         // ascending
+    w[n - 1 - i] = 2.0 / ((1.0 - x * x) * pp * pp);
+  }
+}
+// Gauss-Jacobi(1/2,1/2): weight sqrt(1-t^2)
+static void gauss_cheb2(int n, std::vector<double>& t, std::vector<double>& w) {
+  t.assign(n, 0.0); w.assign(n, 0.0);
+  for (int i = 1; i <= n; ++i) {
+    double th = i * kPi / (n + 1);
+    t[i - 1] = cos(th);
+    w[i - 1] = kPi / (n + 1) * sin(th) * sin(th);
+  }
+}
+
+// ---- labels -------------------------------------------------------------------------------
+static void make_labels(int tree, int n, std::vector<int>& lab, std::vector<int>& deg) {
+  lab.clear(); deg.clear();
+  auto push = [&](int a, int b, int c, int dg) { lab.push_back(a); lab.push_back(b); lab.push_back(c); deg.push_back(dg); };
+  if (tree == TREE_A) {
+    for (int m = 0; m < n; ++m) push(m, 0, 0, m);
+    for (int m = -(n - 1); m < 0; ++m) push(m, 0, 0, -m);
+  } else if (tree == TREE_BA) {
+    for (int q = 0; q < n; ++q) for (int m = -q; m <= q; ++m) push(q, m, 0, q);
+  } else {
+    for (int q = 0; q < n; ++q) for (int l = 0; l <= q; ++l) for (int m = -l; m <= l; ++m) push(q, l, m, q);
+  }
+}
+
+static inline int iabs(int v) { return v < 0 ? -v : v; }
+static inline double isign_even(int e) { return ((e / 2) & 1) ? -1.0 : 1.0; }  // i^e for even e (either sign)
+
+// G3[(l'm'),(lm),l''] real Gaunt-type integral over S^2 of Ybar' conj(Ybar) conj(Ybar''), m'' = m' - m,
+// for l, l' < nmaxA and l'' < nmaxC; evaluated lazily through a dense Pbar table at Gauss-Legendre nodes.
+struct Gaunt3 {
+  int nq, nmax;                     // Pbar table for degrees < nmax
+  std::vector<double> w;            // [nq]
+  std::vector<double> P;            // [nmax][nmax][nq]
+  void init(int nmax_, int nq_) {
+    nmax = nmax_; nq = nq_;
+    std::vector<double> t;
+    gauss_legendre(nq, t, w);
+    P.assign((size_t)nmax * nmax * nq, 0.0);
+    for (int q = 0; q < nq; ++q) {
+      double x = t[q], s = sqrt(1.0 - x * x);
+      for (int n = 0; n < nmax; ++n)
+        for (int m = 0; m <= n; ++m) P[((size_t)n * nmax + m) * nq + q] = pbar_single(n, m, x, s);
+    }
+  }
+  double operator()(int lp, int mp, int l, int m, int lpp) const {
+    int mu = iabs(mp - m);
+    if (lpp < iabs(l - lp) || lpp > l + lp || ((l + lp + lpp) & 1) || mu > lpp) return 0.0;
+    const double* a = &P[((size_t)lp * nmax + iabs(mp)) * nq];
+    const double* b = &P[((size_t)l * nmax + iabs(m)) * nq];
+    const double* c = &P[((size_t)lpp * nmax + mu) * nq];
+    double acc = 0.0;
+    for (int q = 0; q < nq; ++q) acc += w[q] * a[q] * b[q] * c[q];
+    return acc * kInvSqrt2Pi;
+  }
+};
+
+int plan_build_host(biem_plan* p, int tree, int n_end) {
+  if (tree < 0 || tree > 2) { set_error("unsupported coordinate tree id %d (built: a, ba, bba)", tree); return BIEM_ERR_UNSUPPORTED; }
+  if (n_end < 1 || n_end > 4096) { set_error("n_end=%d out of range", n_end); return BIEM_ERR_ARG; }
+  p->tree = tree; p->d = tree_dim(tree); p->n_end = n_end; p->n2 = 2 * n_end - 1;
+  p->H = harm_count(tree, n_end); p->H2 = harm_count(tree, p->n2);
+  p->Cd = pow(2.0 * kPi, 0.5 * p->d) * sqrt(2.0 / kPi);
+  make_labels(tree, n_end, p->labels, p->deg);
+  make_labels(tree, p->n2, p->labels2, p->deg2);
+  const int H = p->H, d = p->d, n = n_end;
+
+  // ---- boundary-data quadrature ----
+  {
+    std::vector<double> t0, w0, t1, w1;
+    const int na = 2 * n;
+    if (tree == TREE_A) {
+      p->Q = na;
+      p->qy.resize((size_t)p->Q * d); p->qw.resize(p->Q);
+      for (int j = 0; j < na; ++j) { double ph = j * kPi / n; p->qy[2 * j] = cos(ph); p->qy[2 * j + 1] = sin(ph); p->qw[j] = kPi / n; }
+    } else if (tree == TREE_BA) {
+      gauss_legendre(n, t0, w0);
+      p->Q = n * na;
+      p->qy.resize((size_t)p->Q * d); p->qw.resize(p->Q);
+      for (int i = 0; i < n; ++i) for (int j = 0; j < na; ++j) {
+        int q = i * na + j; double ph = j * kPi / n, s = sqrt(1.0 - t0[i] * t0[i]);
+        p->qy[3 * q] = t0[i]; p->qy[3 * q + 1] = s * cos(ph); p->qy[3 * q + 2] = s * sin(ph);
+        p->qw[q] = w0[i] * kPi / n;
+      }
+    } else {
+      gauss_cheb2(n, t0, w0); gauss_legendre(n, t1, w1);
+      p->Q = n * n * na;
+      p->qy.resize((size_t)p->Q * d); p->qw.resize(p->Q);
+      for (int i = 0; i < n; ++i) for (int l = 0; l < n; ++l) for (int j = 0; j < na; ++j) {
+        int q = (i * n + l) * na + j; double ph = j * kPi / n;
+        double s0 = sqrt(1.0 - t0[i] * t0[i]), s1 = sqrt(1.0 - t1[l] * t1[l]);
+        p->qy[4 * q] = t0[i]; p->qy[4 * q + 1] = s0 * t1[l]; p->qy[4 * q + 2] = s0 * s1 * cos(ph); p->qy[4 * q + 3] = s0 * s1 * sin(ph);
+        p->qw[q] = w0[i] * w1[l] * kPi / n;
+      }
+    }
+  }
+  // ---- projection matrix W[q][h] = w_q conj(Y_h(y_q)) ----
+  p->W.resize((size_t)p->Q * H * 2);
+  for (int q = 0; q < p->Q; ++q) {
+    Dir dir = make_dir(tree, &p->qy[(size_t)q * d]);
+    for (int h = 0; h < H; ++h) {
+      double re, im;
+      harmonic_single(tree, p->labels[3 * h], p->labels[3 * h + 1], p->labels[3 * h + 2], dir, &re, &im);
+      p->W[((size_t)q * H + h) * 2] = p->qw[q] * re;
+      p->W[((size_t)q * H + h) * 2 + 1] = -p->qw[q] * im;
+    }
+  }
+  // ---- translation terms ----
+  p->ptr.assign((size_t)H * H + 1, 0);
+  p->coef.clear(); p->tidx.clear();
+  if (tree == TREE_A) {
+    const int n2 = p->n2;
+    for (int h = 0; h < H; ++h) for (int hp = 0; hp < H; ++hp) {
+      int m = p->labels[3 * h], mp = p->labels[3 * hp], mu = mp - m;
+      p->coef.push_back(isign_even(iabs(m) + iabs(mu) - iabs(mp)) * kInvSqrt2Pi);
+      p->tidx.push_back(mu >= 0 ? mu : (2 * n2 - 1) + mu);
+      p->ptr[(size_t)h * H + hp + 1] = (uint32_t)p->coef.size();
+    }
+  } else if (tree == TREE_BA) {
+    Gaunt3 G; G.init(p->n2, 2 * n);
+    for (int h = 0; h < H; ++h) for (int hp = 0; hp < H; ++hp) {
+      int q = p->labels[3 * h], m = p->labels[3 * h + 1], qp = p->labels[3 * hp], mp = p->labels[3 * hp + 1], mu = mp - m;
+      for (int q2 = iabs(q - qp); q2 <= q + qp; q2 += 2) {
+        if (q2 < iabs(mu)) continue;
+        double g = G(qp, mp, q, m, q2);
+        p->coef.push_back(isign_even(q + q2 - qp) * g);
+        p->tidx.push_back(q2 * q2 + q2 + mu);
+      }
+      p->ptr[(size_t)h * H + hp + 1] = (uint32_t)p->coef.size();
+    }
+  } else {
+    const int n2 = p->n2;
+    Gaunt3 G; G.init(n2, 2 * n);
+    // Abar[n][l][q] at Gauss-Chebyshev-2 nodes, degrees < n2
+    std::vector<double> tc, wc; gauss_cheb2(2 * n, tc, wc);
+    const int nq = 2 * n;
+    std::vector<double> Ab((size_t)n2 * n2 * nq, 0.0);
+    for (int qd = 0; qd < nq; ++qd) {
+      double x = tc[qd], s = sqrt(1.0 - x * x);
+      for (int l = 0; l < n2; ++l) {
+        double sl = 1.0; for (int i = 0; i < l; ++i) sl *= s;
+        for (int q = l; q < n2; ++q) Ab[((size_t)q * n2 + l) * nq + qd] = sl * gbar_single(q - l, l, x);
+      }
+    }
+    auto off = [](int q) { return q * (q + 1) * (2 * q + 1) / 6; };
+    for (int h = 0; h < H; ++h) for (int hp = 0; hp < H; ++hp) {
+      int q = p->labels[3 * h], l = p->labels[3 * h + 1], m = p->labels[3 * h + 2];
+      int qp = p->labels[3 * hp], lp = p->labels[3 * hp + 1], mp = p->labels[3 * hp + 2], mu = mp - m;
+      const double* a = &Ab[((size_t)qp * n2 + lp) * nq];
+      const double* b = &Ab[((size_t)q * n2 + l) * nq];
+      for (int q2 = iabs(q - qp); q2 <= q + qp; q2 += 2) {
+        for (int l2 = iabs(l - lp); l2 <= l + lp && l2 <= q2; l2 += 2) {
+          if (l2 < iabs(mu)) continue;
+          double g3 = G(lp, mp, l, m, l2);
+          if (g3 == 0.0) continue;
+          const double* c = &Ab[((size_t)q2 * n2 + l2) * nq];
+          double a4 = 0.0;
+          for (int qd = 0; qd < nq; ++qd) a4 += wc[qd] * a[qd] * b[qd] * c[qd];
+          double v = a4 * g3;
+          if (fabs(v) < 1e-14) continue;   // vanishes by a selection rule; only quadrature rounding is left
+          p->coef.push_back(isign_even(q + q2 - qp) * v);
+          p->tidx.push_back(off(q2) + l2 * l2 + l2 + mu);
+        }
+      }
+      p->ptr[(size_t)h * H + hp + 1] = (uint32_t)p->coef.size();
+    }
+  }
+  return BIEM_OK;
+}
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return BIEM_ERR_HIP; } } while (0)
+
+template <class T> static int up(T** dst, const std::vector<T>& src) {
+  if (src.empty()) { *dst = nullptr; return BIEM_OK; }
+  HIPCHK(hipMalloc((void**)dst, src.size() * sizeof(T)));
+  HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return BIEM_OK;
+}
+
+int plan_upload(biem_plan* p) {
+  if (p->device >= 0) return BIEM_OK;
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  int rc;
+  if ((rc = up(&p->d_labels, p->labels))) return rc;
+  if ((rc = up(&p->d_deg, p->deg))) return rc;
+  if ((rc = up(&p->d_labels2, p->labels2))) return rc;
+  if ((rc = up(&p->d_deg2, p->deg2))) return rc;
+  if ((rc = up(&p->d_W, p->W))) return rc;
+  if ((rc = up(&p->d_ptr, p->ptr))) return rc;
+  if ((rc = up(&p->d_coef, p->coef))) return rc;
+  if ((rc = up(&p->d_tidx, p->tidx))) return rc;
+  p->device = dev;
+  return BIEM_OK;
+}
+
+void plan_free(biem_plan* p) {
+  if (p->device >= 0) {
+    (void)hipFree(p->d_labels); (void)hipFree(p->d_deg); (void)hipFree(p->d_labels2); (void)hipFree(p->d_deg2);
+    (void)hipFree(p->d_W); (void)hipFree(p->d_ptr); (void)hipFree(p->d_coef); (void)hipFree(p->d_tidx);
+  }
+  delete p;
+}
+
+}  // namespace biem

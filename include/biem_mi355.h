@@ -1,0 +1,158 @@
+/*
+ * biem_mi355.h  --  C ABI of libbiem_mi355.so: the biem() dense assembly-and-solve hot path on MI355X.
+ *
+ * The reference (ultrasphere-dev/biem-helmholtz-sphere v1.2.0) is pure Python and has no FFI; the
+ * boundary it offers for this path is the Python signature of biem() (src/biem_helmholtz_sphere/
+ * _biem.py:453-469).  Every entry point below replaces a span of that function (or of biem_u) and
+ * cites it.  The host layer (biem_helmholtz_sphere_amd/_biem.py) binds these with ctypes; what a
+ * maintainer of the reference would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all sizes are int / long long / size_t; complex128 = 2 doubles.
+ *   - pointers named d_* are DEVICE pointers (HIP, gfx950) owned by the caller; h_* are host pointers.
+ *   - every function returns a status (0 = BIEM_OK) and never throws; text via biem_last_error().
+ *   - all device work is enqueued on the caller-supplied hipStream_t (passed as void*), nothing
+ *     synchronises unless stated; the library keeps no global mutable state (error text is
+ *     thread-local).  Workspaces are caller-allocated; sizes come from the *_bytes functions.
+ *   - `nb` = number of independent (k, eta, incidence) systems in the call (the batch "..." of
+ *     _biem.py:80-91), B = balls, H = harmonics of degree < n_end per ball, N = B*H,
+ *     Npad = N rounded up (biem_lu_npad) - the LU works on an identity-padded Npad x Npad system.
+ *   - order of the harm axis: see biem_plan_labels (this project's choice; the reference's order is
+ *     decided inside un-vendored ush.flatten_harmonics and is not pinned by any fixture).
+ */
+#ifndef BIEM_MI355_H
+#define BIEM_MI355_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes */
+#define BIEM_OK 0
+#define BIEM_ERR_ARG 1          /* bad argument (shape, null pointer, flag) */
+#define BIEM_ERR_HIP 2          /* a HIP runtime call failed */
+#define BIEM_ERR_UNSUPPORTED 3  /* coordinate tree / size not built */
+#define BIEM_ERR_ALLOC 4
+#define BIEM_ERR_NO_DEVICE 5    /* no gfx950 device visible */
+
+/* coordinate trees (ultrasphere.create_from_branching_types strings) */
+#define BIEM_TREE_A 0    /* "a"   d=2 */
+#define BIEM_TREE_BA 1   /* "ba"  d=3, polar axis x0 */
+#define BIEM_TREE_BBA 2  /* "bba" d=4 */
+
+/* fill scalings */
+#define BIEM_FILL_REFERENCE 0    /* A = blc_{n'} * { diag(alpha h + beta k h') | (S|R)^T (alpha j + beta k j') }  (_biem.py:745-792) */
+#define BIEM_FILL_EQUILIBRATED 1 /* M = I + (S|R)^T (alpha j+beta k j')_row / (alpha h+beta k h')_col : what the LU factors */
+
+/* uscat flags */
+#define BIEM_USCAT_FAR_FIELD 1
+#define BIEM_USCAT_PER_BALL 2
+#define BIEM_USCAT_KIND_INNER 4
+#define BIEM_USCAT_POINTS_BATCHED 8 /* points carry their own batch axis (expand_x=False, _biem.py:879-883) */
+
+typedef struct biem_plan biem_plan; /* opaque: host+device tables of one (tree, n_end) */
+
+int biem_version(void);
+const char* biem_last_error(void);
+/* number of visible HIP devices; BIEM_ERR_NO_DEVICE if none */
+int biem_device_count(int* n);
+
+/* ---- plan: k- and geometry-independent tables (replaces the table side of ush.expand /
+ *      ush.harmonics_translation_coef / ush.index_array_harmonics, _biem.py:627,651,697,720) ---- */
+/* host-only tables (no GPU needed): labels, quadrature, projection matrix, translation terms */
+int biem_plan_create_host(int tree, int n_end, biem_plan** plan);
+/* upload the tables to the current HIP device (idempotent) */
+int biem_plan_upload(biem_plan* plan);
+/* = create_host + upload */
+int biem_plan_create(int tree, int n_end, biem_plan** plan);
+int biem_plan_destroy(biem_plan* plan);
+/* d, H (degree < n_end), Q quadrature points per ball, H2 (degree < 2 n_end - 1), number of translation terms */
+int biem_plan_info(const biem_plan* plan, int* d, int* n_harm, int* n_quad, int* n_harm2, long long* n_terms);
+/* h_labels[H][3]: a:(m,0,0)  ba:(n,m,0)  bba:(n,l,m);  h_deg[H]: degree n */
+int biem_plan_labels(const biem_plan* plan, int* h_labels, int* h_deg);
+/* unit vectors y[Q][d] and weights w[Q] of the boundary-data rule (ush.expand(n=n_end)) */
+int biem_plan_quadrature(const biem_plan* plan, double* h_y, double* h_w);
+/* projection matrix W[Q][H] (complex128, host copy):  f_h = sum_q W[q][h] g(y_q),  W = w_q conj(Y_h(y_q)) */
+int biem_plan_projection(const biem_plan* plan, double* h_W);
+/* translation terms in CSR over entries e = h*H + h' (row h = test index, column h' = unknown):
+ * (S|R)_{h'->h}(t) = sum_{p in [ptr[e],ptr[e+1])} coef[p] * T[tidx[p]],  T[l] = C_d h_{n''}(k|t|) Y_l(t^), l over labels of degree < 2 n_end - 1 */
+int biem_plan_terms(const biem_plan* plan, long long* h_ptr /*[H*H+1]*/, double* h_coef, int* h_tidx);
+
+/* ---- special functions on the device, exposed for parity tests (ultrasphere.shn1 / potential_coef) ---- */
+/* z[i][0..nmax] (j) and [nmax+1 .. 2nmax+1] (y): d-dimensional spherical Bessel functions at x[i] */
+int biem_radial(int d, int nmax, int count, const double* d_x, double* d_out /*[count][2][nmax+1]*/, void* stream);
+/* Y[p][h] (complex128) at directions d_u[p][d] (need not be normalised) for all labels of degree < n_end */
+int biem_harmonics(const biem_plan* plan, int count, const double* d_u, double* d_Y /*[count][H] c128*/, void* stream);
+
+/* ---- per-ball tables (ush.harmonics_regular_singular_component + potential_coef, _biem.py:723-789) ----
+ * d_tab[nb][B][3][n_end] complex128: [0] gj = alpha j_n + beta k j_n', [1] gh = alpha h_n + beta k h_n', [2] blc_n = dlc - i eta slc
+ * geometry arrays are [nb][B]... when geom_batched != 0, else [B]... shared by all systems; alpha/beta likewise (ab_batched). */
+int biem_ball_tables(const biem_plan* plan, int nb, int B, const double* d_k, const double* d_eta,
+                     const double* d_radii, int geom_batched, const double* d_alpha /*c128*/, const double* d_beta /*c128*/,
+                     int ab_batched, double* d_tab, void* stream);
+
+/* ---- right-hand side (ush.expand, _biem.py:627-639): the incident field stays a Python callable; only its samples
+ *      g[row][q] = (-alpha u_in - beta d_n u_in)(c_b + rho_b y_q), row = s*B + b, cross the ABI.
+ *      f element (row, h) is written to d_f[(row / B) * sys_stride + ((row % B) * H + h) * elem_stride]  (complex128 units) ---- */
+int biem_rhs_project(const biem_plan* plan, int nb, int B, const double* d_g /*[nb*B][Q] c128*/, double* d_f,
+                     long long sys_stride, long long elem_stride, void* stream);
+
+/* ---- matrix fill (ush.harmonics_translation_coef + the where/create_diagonal/moveaxis block, _biem.py:694-792) ----
+ * Writes the N x N matrix of every system, row-major [b][h][b'][h'] with leading dimension lda (complex128 units),
+ * system s at d_A + 2*s*sys_stride doubles.  When lda > N / rows_pad > N the caller gets an identity-padded
+ * Npad x Npad block (columns >= Npad are left untouched: that is where the LU keeps right-hand sides).
+ * d_tab from biem_ball_tables.  Workspace: biem_fill_workspace_bytes. */
+size_t biem_fill_workspace_bytes(const biem_plan* plan, int nb, int B);
+int biem_fill(const biem_plan* plan, int nb, int B, const double* d_k, const double* d_centers /*[nb or 1][B][d]*/,
+              int geom_batched, const double* d_tab, int scaling, double* d_A, long long lda, long long sys_stride,
+              int n_pad, void* d_work, size_t work_bytes, void* stream);
+
+/* ---- dense complex LU (batch_tensorsolve.btensorsolve -> linalg.solve, _biem.py:797) ----
+ * Right-looking blocked LU with partial (row) pivoting; trailing updates are zgemm on v_mfma_f64_16x16x4_f64.
+ * The system is the augmented row-major [A | F]: Npad rows, Npad + nrhs columns, leading dimension lda >= Npad + nrhs.
+ * biem_lu_factor_solve overwrites F with the solution (forward elimination rides in the trailing update, then a
+ * blocked back substitution); A is overwritten by U and the un-permuted multipliers. */
+int biem_lu_npad(int N);
+size_t biem_lu_workspace_bytes(int nb, int n_pad, int nrhs);
+int biem_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride,
+                         int* d_ipiv /*[nb][n_pad]*/, int* d_info /*[nb]*/, void* d_work, size_t work_bytes, void* stream);
+
+/* density[s][b][h] = x / (gh * blc): the reference's `density` from the equilibrated unknowns (also the
+ * single-ball shortcut _biem.py:648-691 with x = f).  x element (s, i) at d_x[s*sys_stride + i*elem_stride]. */
+int biem_density(const biem_plan* plan, int nb, int B, const double* d_x, long long sys_stride, long long elem_stride,
+                 const double* d_tab, double* d_density /*[nb][B][H] c128*/, void* stream);
+
+/* ---- field evaluation (biem_u, _biem.py:822-977) ----
+ * d_points[d][P] (or [d][P][nb] with BIEM_USCAT_POINTS_BATCHED); out[P][nb] or [P][nb][B] (per ball), complex128.
+ * Workspace: biem_uscat_workspace_bytes (holds density * blc). */
+size_t biem_uscat_workspace_bytes(const biem_plan* plan, int nb, int B);
+int biem_uscat(const biem_plan* plan, int nb, int B, int P, const double* d_k, const double* d_eta,
+               const double* d_centers, const double* d_radii, int geom_batched, const double* d_density,
+               const double* d_points, int flags, double* d_out, void* d_work, size_t work_bytes, void* stream);
+
+/* ---- one call for the whole path: ball tables + fill (equilibrated) + LU + density, systems processed in
+ *      chunks of `chunk` resident matrices (0 = choose).  d_g as in biem_rhs_project. ---- */
+size_t biem_solve_workspace_bytes(const biem_plan* plan, int nb, int B, int chunk);
+int biem_solve(const biem_plan* plan, int nb, int B, const double* d_k, const double* d_eta, const double* d_centers,
+               const double* d_radii, int geom_batched, const double* d_alpha, const double* d_beta, int ab_batched,
+               const double* d_g, double* d_density, int* d_info, int chunk, void* d_work, size_t work_bytes, void* stream);
+
+/* ---- per-kernel-class timing with HIP events on the launch stream (thread-local; used by bench.py for the
+ *      live `roofline` figures).  Between begin and end every launch of the calling thread is bracketed by two
+ *      events; end synchronises on them and returns, per class, elapsed ms, algorithmic work and launch count.
+ *      Classes: 0 tables, 1 fill (work = bytes written), 2 rhs, 3 panel, 4 swap, 5 trsm, 6 gemm (work = real
+ *      flops, 8 per complex multiply-add), 7 back substitution, 8 other. */
+#define BIEM_PROFILE_CLASSES 9
+int biem_profile_begin(void);
+int biem_profile_end(double* ms /*[9]*/, double* work /*[9]*/, long long* launches /*[9]*/);
+
+/* ---- microbenchmarks used by bench.py / DESIGN.md (peak checks, not part of the path) ---- */
+/* issues `iters` dependent-free v_mfma_f64_16x16x4_f64 per wave on every SIMD; returns achieved FLOP/s */
+int biem_bench_mfma_f64(int iters, double* tflops, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIEM_MI355_H */

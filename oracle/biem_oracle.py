@@ -314,6 +314,36 @@ def _theta4(n_end: int):
     return A4, nl, Ab
 
 
+@lru_cache(maxsize=4)
+def _terms3(n_end: int):
+    """Non-zero triple integrals of `ba` as a term list: entry h'*H + h, flat index into T[n'', mu], signed coefficient."""
+    G, nn, mm = _gaunt3(n_end)
+    n2 = 2 * n_end - 1
+    hp, h, n3 = np.nonzero(G)
+    sign = np.real(1j ** ((nn[h] + n3 - nn[hp]) % 4))              # i^{n+n''-n'} is real wherever G != 0 (parity rule)
+    mu = mm[hp] - mm[h] + (n2 - 1)
+    H = len(nn)
+    return (hp * H + h).astype(np.int64), (n3 * (2 * n2 - 1) + mu).astype(np.int64), G[hp, h, n3] * sign
+
+
+def translation_SR_ba_dense(n_end: int, k: float, t: np.ndarray) -> np.ndarray:
+    """Dense-table evaluation of the 3-D closed form; cross-check of the term-list path in :func:`translation_SR`."""
+    t = np.asarray(t, dtype=np.float64)
+    r = float(np.linalg.norm(t))
+    n2 = 2 * n_end - 1
+    j, y, _, _ = radial(n2 - 1, 3, k * r)
+    hn = j + 1j * y
+    u = t / r
+    G, nn, mm = _gaunt3(n_end)
+    Pb = _pbar(n2 - 1, np.array(min(1.0, max(-1.0, u[0]))))
+    mus = np.arange(-(n2 - 1), n2)
+    T = hn[:, None] * Pb[:, np.abs(mus)] * np.exp(1j * mus * math.atan2(u[2], u[1]))[None, :] / math.sqrt(2 * math.pi)
+    Tg = T[:, mm[:, None] - mm[None, :] + (n2 - 1)]                 # [n'', h', h]
+    n3 = np.arange(n2)[:, None, None]
+    sign = np.real(1j ** ((nn[None, None, :] + n3 - nn[None, :, None]) % 4))
+    return 4 * math.pi * np.sum(np.moveaxis(G, -1, 0) * sign * Tg, axis=0)
+
+
 def translation_SR(tr: Tree, n_end: int, k: float, t: np.ndarray) -> np.ndarray:
     """SR[h', h] = (S|R)_{h' -> h}(t): S_{h'}(r + t) = sum_h SR[h', h] R_h(r) for |r| < |t|.
 
@@ -330,18 +360,16 @@ def translation_SR(tr: Tree, n_end: int, k: float, t: np.ndarray) -> np.ndarray:
     hn = j + 1j * y
     u = t / r
     if tr.name == "ba":
-        G, nn, mm = _gaunt3(n_end)
+        ent, tix, cf = _terms3(n_end)
         ct = min(1.0, max(-1.0, u[0]))
         phi = math.atan2(u[2], u[1])
         Pb = _pbar(n2 - 1, np.array(ct))                            # [n'', mu]
         mus = np.arange(-(n2 - 1), n2)
         T = hn[:, None] * Pb[:, np.abs(mus)] * np.exp(1j * mus * phi)[None, :] / math.sqrt(2 * math.pi)  # [n'', mu]
-        mu = mm[:, None] - mm[None, :] + (n2 - 1)
-        Tg = T[:, mu]                                               # [n'', h', h]
-        n3 = np.arange(n2)[:, None, None]
-        sign = np.real(1j ** ((nn[None, None, :] + n3 - nn[None, :, None]) % 4 + 0))
-        # i^{n+n''-n'} is real wherever G != 0 (parity rule)
-        return Cd * np.sum(np.moveaxis(G, -1, 0) * sign * Tg, axis=0)
+        contrib = cf * T.reshape(-1)[tix]
+        H = n_end * n_end
+        SR = np.bincount(ent, weights=contrib.real, minlength=H * H) + 1j * np.bincount(ent, weights=contrib.imag, minlength=H * H)
+        return Cd * SR.reshape(H, H)
     if tr.name == "bba":
         A4, nl, _ = _theta4(n_end)
         G3, ll3, mm3 = _gaunt3(n_end)                               # labels (l, m), l < n_end

@@ -1,0 +1,313 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the reference's goldens.
+
+Tolerances (complex fp64): BASELINE north_star asks <= 1e-10 relative on u_scat; component checks are tighter.
+"""
+import csv
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import biem_oracle as O  # noqa: E402  (test infrastructure: the checker)
+
+
+@pytest.fixture(scope="module")
+def amd():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import biem_helmholtz_sphere_amd as amd
+
+    return amd
+
+
+@pytest.fixture(scope="module")
+def lib(amd):
+    from biem_helmholtz_sphere_amd import _lib as L
+
+    return L.load(), L
+
+
+def _dev(a, dtype=torch.float64):
+    return torch.as_tensor(np.array(a), device="cuda").to(dtype).contiguous()
+
+
+# ---------------------------------------------------------------------------- special functions
+@pytest.mark.parametrize("d", [2, 3, 4])
+def test_radial_device_vs_scipy(lib, d):
+    l, L = lib
+    nmax = 60
+    xs = np.concatenate([np.geomspace(0.05, 150, 80), [1.0, 2.404825557695773, 3.141592653589793, 136.0]])
+    x = _dev(xs)
+    out = torch.zeros((len(xs), 2, nmax + 1), dtype=torch.float64, device="cuda")
+    L.check(l.biem_radial(d, nmax, len(xs), x.data_ptr(), out.data_ptr(), None))
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for i, xv in enumerate(xs):
+        j, y, _, _ = O.radial(nmax, d, xv)
+        ok = np.isfinite(y) & (np.abs(y) < 1e290)
+        env = np.abs(j + 1j * y)[ok]
+        assert np.max(np.abs(out[i, 0][ok] - j[ok]) / env) < 2e-12 * max(1.0, xv / 10), (d, xv)
+        assert np.max(np.abs(out[i, 1][ok] - y[ok]) / env) < 2e-12 * max(1.0, xv / 10), (d, xv)
+        # small regular functions keep RELATIVE accuracy (they scale the matrix rows)
+        small = ok & (np.arange(nmax + 1) > xv) & (np.abs(j) > 1e-280)
+        if small.any():
+            assert np.max(np.abs(out[i, 0][small] / j[small] - 1)) < 1e-11, (d, xv)
+
+
+@pytest.mark.parametrize("tree,n_end", [("a", 9), ("ba", 7), ("bba", 5)])
+def test_harmonics_device_vs_oracle(lib, tree, n_end):
+    l, L = lib
+    plan = C.c_void_p()
+    L.check(l.biem_plan_create(L.TREE_IDS[tree], n_end, C.byref(plan)))
+    tr = O.tree(tree)
+    rng = np.random.default_rng(0)
+    u = rng.normal(size=(50, tr.d))
+    u[0] = 0; u[0, 0] = 1.0           # poles
+    u[1] = 0; u[1, 0] = -2.0
+    u[2] = 0; u[2, 1] = 1.5
+    H = tr.n_harm(n_end)
+    Y = torch.zeros((50, H), dtype=torch.complex128, device="cuda")
+    L.check(l.biem_harmonics(plan, 50, _dev(u).data_ptr(), Y.data_ptr(), None))
+    torch.cuda.synchronize()
+    Yo = tr.harmonics(u / np.linalg.norm(u, axis=-1, keepdims=True), n_end).T
+    assert np.abs(Y.cpu().numpy() - Yo).max() < 1e-12
+    l.biem_plan_destroy(plan)
+
+
+# ---------------------------------------------------------------------------- fill
+def _rand_geometry(rng, B, d, rmin=0.4, rmax=1.0, gap=1.15):
+    cen, rad = [], []
+    while len(cen) < B:
+        c = rng.uniform(-4, 4, size=d)
+        r = rng.uniform(rmin, rmax)
+        if all(np.linalg.norm(c - c2) > gap * (r + r2) for c2, r2 in zip(cen, rad)):
+            cen.append(c)
+            rad.append(r)
+    return np.array(cen), np.array(rad)
+
+
+@pytest.mark.parametrize("tree,n_end,B", [("a", 6, 3), ("ba", 5, 3), ("bba", 4, 2), ("ba", 9, 2)])
+def test_fill_reference_scaling_vs_oracle(amd, tree, n_end, B):
+    """`matrix` attribute (reference scaling, _biem.py:745-792) element-wise against the oracle, batch of 2 k's."""
+    rng = np.random.default_rng(5)
+    tr = O.tree(tree)
+    cen, rad = _rand_geometry(rng, B, tr.d)
+    ks = np.array([0.9, 2.3])
+    eta = np.array([1.0, 0.6])
+    alpha, beta = 1.0 + 0.25j, 0.4 - 0.1j
+    c = amd.create_from_branching_types(tree)
+    calc = amd.biem(c, centers=_dev(cen)[None].expand(2, B, tr.d), radii=_dev(rad)[None].expand(2, B), k=_dev(ks), eta=_dev(eta),
+                    n_end=n_end, alpha=alpha, beta=beta)
+    assert calc.density is None
+    M = calc.matrix.cpu().numpy()
+    H = tr.n_harm(n_end)
+    assert M.shape == (2, B, H, B, H)
+    for s in range(2):
+        A, _ = O.assemble(tr, n_end, ks[s], eta[s], cen, rad, np.full(B, alpha), np.full(B, beta))
+        scale = np.abs(A).max(axis=(2, 3), keepdims=True) * 0 + np.abs(A)  # elementwise where nonzero
+        err = np.abs(M[s] - A)
+        # relative to the larger of the entry itself and 1e-14 * the row-block scale
+        ref = np.maximum(np.abs(A), 1e-30)
+        nz = np.abs(A) > 1e-200
+        assert np.max(err[nz] / ref[nz]) < 5e-11, (tree, s)
+        assert np.all(M[s][~nz] == 0)
+
+
+# ---------------------------------------------------------------------------- LU
+@pytest.mark.parametrize("N,nb,nrhs", [(64, 3, 1), (72, 2, 2), (200, 2, 1), (576, 1, 3), (1000, 2, 1)])
+def test_lu_factor_solve_vs_numpy(lib, N, nb, nrhs):
+    l, L = lib
+    rng = np.random.default_rng(N)
+    npad = l.biem_lu_npad(N)
+    lda = npad + nrhs
+    A = np.zeros((nb, npad, lda), dtype=np.complex128)
+    As = rng.normal(size=(nb, N, N)) + 1j * rng.normal(size=(nb, N, N))
+    As[0] += 0 if N < 100 else 0                      # plain Gaussian: pivoting is exercised
+    Fs = rng.normal(size=(nb, N, nrhs)) + 1j * rng.normal(size=(nb, N, nrhs))
+    A[:, :N, :N] = As
+    for i in range(N, npad):
+        A[:, i, i] = 1.0
+    A[:, :N, npad:] = Fs
+    dA = _dev(A, torch.complex128)
+    ipiv = torch.zeros((nb, npad), dtype=torch.int32, device="cuda")
+    info = torch.ones(nb, dtype=torch.int32, device="cuda")
+    wb = l.biem_lu_workspace_bytes(nb, npad, nrhs)
+    work = torch.empty(wb, dtype=torch.uint8, device="cuda")
+    L.check(l.biem_lu_factor_solve(nb, npad, nrhs, dA.data_ptr(), lda, npad * lda, ipiv.data_ptr(), info.data_ptr(), work.data_ptr(), wb, None))
+    torch.cuda.synchronize()
+    X = dA.cpu().numpy()[:, :N, npad:]
+    assert (info.cpu().numpy() == 0).all()
+    for s in range(nb):
+        Xo = np.linalg.solve(As[s], Fs[s])
+        # backward-error style check and forward check (Gaussian matrices: cond ~ N)
+        res = np.abs(As[s] @ X[s] - Fs[s]).max() / (np.abs(As[s]).sum(axis=1).max() * np.abs(X[s]).max())
+        assert res < 1e-13, (N, s, res)
+        assert np.abs(X[s] - Xo).max() / np.abs(Xo).max() < 1e-9
+    if N > npad - 1:
+        return
+    # padded rows stay zero in the solution
+    assert np.abs(dA.cpu().numpy()[:, N:, npad:]).max() == 0
+
+
+def test_lu_singular_reports_info(lib):
+    l, L = lib
+    N = 64
+    A = np.zeros((1, N, N + 1), dtype=np.complex128)
+    A[0, :, :N] = np.eye(N)
+    A[0, 10, 10] = 0.0
+    dA = _dev(A, torch.complex128)
+    ipiv = torch.zeros((1, N), dtype=torch.int32, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    wb = l.biem_lu_workspace_bytes(1, N, 1)
+    work = torch.empty(wb, dtype=torch.uint8, device="cuda")
+    L.check(l.biem_lu_factor_solve(1, N, 1, dA.data_ptr(), N + 1, N * (N + 1), ipiv.data_ptr(), info.data_ptr(), work.data_ptr(), wb, None))
+    torch.cuda.synchronize()
+    assert int(info.cpu()[0]) == 11
+
+
+# ---------------------------------------------------------------------------- end to end
+def _oracle_case(tree, cen, rad, k, n_end, eta, alpha, beta, direction, x):
+    uin, ugr = O.plane_wave(k, direction)
+    res = O.solve_biem(tree, centers=cen, radii=rad, k=k, n_end=n_end, eta=eta, alpha=alpha, beta=beta, uin=uin, uin_grad=ugr)
+    return res, O.uscat(res, x)
+
+
+@pytest.mark.parametrize(
+    "tree,B,n_end,alpha,beta",
+    [("a", 4, 10, 1.0, 0.0), ("a", 3, 8, 1.0, 1.0), ("ba", 2, 6, 1.0, 0.0), ("ba", 3, 7, 0.0, 1.0),
+     ("ba", 3, 6, 1.0 + 0.5j, 0.3 - 0.2j), ("bba", 2, 4, 1.0, 0.0), ("bba", 2, 4, 1.0, 1.0)],
+)
+def test_biem_end_to_end_vs_oracle(amd, tree, B, n_end, alpha, beta):
+    rng = np.random.default_rng(11)
+    tr = O.tree(tree)
+    d = tr.d
+    cen, rad = _rand_geometry(rng, B, d)
+    k, eta = 1.4, 1.3
+    direction = rng.normal(size=d)
+    x = rng.normal(size=(7, d)) * 6.0
+    x = x[[all(np.linalg.norm(p - c) > r for c, r in zip(cen, rad)) for p in x]]
+    res, uo = _oracle_case(tree, cen, rad, k, n_end, eta, alpha, beta, direction, x)
+    c = amd.create_from_branching_types(tree)
+    uin, ugr = amd.plane_wave(k=_dev(k), direction=_dev(direction))
+    calc = amd.biem(c, centers=_dev(cen), radii=_dev(rad), k=_dev(k), eta=_dev(eta), n_end=n_end, alpha=alpha, beta=beta,
+                    uin=uin, uin_grad=ugr)
+    dens = calc.density.cpu().numpy()
+    assert dens.shape == res.density.shape
+    # density: relative to the per-degree scale (entries span many decades)
+    assert np.max(np.abs(dens - res.density) / (np.abs(res.density) + 1e-12 * np.abs(res.density).max())) < 1e-8
+    u = calc.uscat(_dev(x.T)).cpu().numpy()
+    assert np.max(np.abs(u - uo) / np.abs(uo)) < 1e-10
+    # per-ball and far field
+    upb = calc.uscat(_dev(x.T), per_ball=True).cpu().numpy()
+    assert np.max(np.abs(upb - O.uscat(res, x, per_ball=True))) < 1e-10 * np.abs(uo).max()
+    xf = x / np.linalg.norm(x, axis=-1, keepdims=True)
+    uf = calc.uscat(_dev(xf.T), far_field=True).cpu().numpy()
+    ufo = O.uscat(res, xf, far_field=True)
+    assert np.max(np.abs(uf - ufo) / np.abs(ufo).max()) < 1e-10
+
+
+def test_single_ball_shortcut_and_force_matrix(amd):
+    tr = O.tree("ba")
+    cen, rad = np.array([[0.3, -0.2, 0.1]]), np.array([0.8])
+    k, n_end = 2.0, 8
+    x = np.array([[2.0, 0.5, -1.0], [0.0, 3.0, 0.0]])
+    res, uo = _oracle_case("ba", cen, rad, k, n_end, 1.0, 1.0, 0.5, [1.0, 0.2, 0.0], x)
+    c = amd.create_from_branching_types("ba")
+    uin, ugr = amd.plane_wave(k=_dev(k), direction=_dev([1.0, 0.2, 0.0]))
+    kw = dict(centers=_dev(cen), radii=_dev(rad), k=_dev(k), n_end=n_end, alpha=1.0, beta=0.5, uin=uin, uin_grad=ugr)
+    a = amd.biem(c, **kw)
+    b = amd.biem(c, force_matrix=True, **kw)
+    assert a.matrix is None and b.matrix is not None
+    for calc in (a, b):
+        assert np.max(np.abs(calc.uscat(_dev(x.T)).cpu().numpy() - uo) / np.abs(uo)) < 1e-10
+
+
+def test_uscat_nan_mask_and_inner_kind(amd):
+    c = amd.create_from_branching_types("a")
+    uin, _ = amd.plane_wave(k=_dev(1.0), direction=_dev([1.0, 0.0]))
+    cen = np.array([[0.0, 2.0], [0.0, -2.0]])
+    calc = amd.biem(c, centers=_dev(cen), radii=_dev([1.0, 1.0]), k=_dev(1.0), n_end=5, uin=uin)
+    x = _dev(np.array([[0.0, 0.0], [0.0, 2.2], [5.0, 0.0]]).T)
+    u = calc.uscat(x).cpu().numpy()
+    assert np.isfinite(u[0]) and np.isnan(u[1]) and np.isfinite(u[2])
+    assert np.isnan(calc.uscat(x, per_ball=True).cpu().numpy()[1]).all()
+    with pytest.raises(ValueError):
+        amd.BIEMResultCalculator(c=c, centers=calc.centers, radii=calc.radii, k=calc.k, n_end=5, eta=calc.eta, kind="outer").uscat(x)
+
+
+# ---------------------------------------------------------------------------- goldens straight through the product
+def test_readme_doctest_numpy_in_numpy_out(amd):
+    """README.md:117-124 of the reference, verbatim call pattern with NumPy arrays."""
+    xp = np
+    c = amd.create_from_branching_types("ba")
+    uin, uin_grad = amd.plane_wave(k=xp.asarray(1.0), direction=xp.asarray((1.0, 0.0, 0.0)))
+    calc = amd.biem(c, uin=uin, uin_grad=uin_grad, k=xp.asarray(1.0), n_end=6, eta=xp.asarray(1.0),
+                    centers=xp.asarray(((0.0, 2.0, 0.0), (0.0, -2.0, 0.0))), radii=xp.asarray((1.0, 1.0)), kind="outer")
+    u = calc.uscat(xp.asarray((0.0, 0.0, 0.0)))
+    assert isinstance(u, np.ndarray)
+    assert complex(xp.round(u, 6)) == pytest.approx(-0.741333 - 0.669657j, abs=1e-12)
+    # 17-digit golden, accuracy_k_ba.csv:52
+    assert abs(complex(u) - (-0.74133301331334 - 0.6696574197988229j)) < 1e-12
+
+
+def test_golden_rows_through_gpu(amd, golden_dir):
+    def run(tree, n_end, k_op, cen):
+        c = amd.create_from_branching_types(tree)
+        d = c.c_ndim
+        e0 = np.zeros(d); e0[0] = 1.0
+        uin, _ = amd.plane_wave(k=_dev(1.0), direction=_dev(e0))      # incident k = 1 quirk (cli.py:238-244)
+        calc = amd.biem(c, centers=_dev(cen), radii=_dev(np.ones(len(cen))), k=_dev(k_op), eta=_dev(1.0), n_end=n_end, uin=uin)
+        return complex(calc.uscat(_dev(np.zeros(d))).cpu().numpy())
+
+    n = 0
+    with open(os.path.join(golden_dir, "jascome_output.csv")) as f:
+        for r in csv.DictReader(f):
+            bt, n_end = r["branching_types"], int(r["n_end"])
+            if bt in ("a", "ba", "bba") and n_end <= 6:
+                tol = 2e-12 if n_end == 6 else 1e-12        # triplet drift of the reference itself at n_end = 6
+                assert abs(run(bt, n_end, 1.0, O.grid_centers(0, O.tree(bt).d)) - complex(r["uscat"])) < tol, (bt, n_end)
+                n += 1
+    with open(os.path.join(golden_dir, "accuracy_k_ba.csv")) as f:
+        for i, r in enumerate(csv.DictReader(f)):
+            n_end = int(r["n_end"])
+            if i % 23 == 0 and n_end <= 30:
+                d = O.tree(r["branching_types"]).d
+                assert abs(run(r["branching_types"], n_end, float(r["k"]), O.grid_centers(0, d)) - complex(r["uscat"])) < 1e-11, (r["branching_types"], n_end, r["k"])
+                n += 1
+    half = {4: 1, 16: 2, 64: 4}
+    with open(os.path.join(golden_dir, "accuracy_n_balls_a.csv")) as f:
+        for r in csv.DictReader(f):
+            nbal, n_end = int(r["n_balls"]), int(r["n_end"])
+            if nbal in half and n_end in (3, 13, 32, 64) and nbal * (2 * n_end - 1) <= 2100:
+                assert abs(run("a", n_end, 1.0, O.grid_centers(half[nbal], 2)) - complex(r["uscat"])) < 1e-11, (nbal, n_end)
+                n += 1
+    assert n > 40
+
+
+def test_batch_of_wavenumbers_matches_one_by_one(amd):
+    """cfg-3 style batch (k sweep, shared geometry) == the same systems solved one at a time; oracle at two of them."""
+    c = amd.create_from_branching_types("ba")
+    cen = O.grid_centers(1, 3)
+    B = len(cen)
+    ks = np.linspace(0.5, 3.0, 5)
+    dirs = np.tile(np.array([[1.0], [0.0], [0.0]]), (1, 5))
+    uin, _ = amd.plane_wave(k=_dev(ks), direction=_dev(dirs))
+    calc = amd.biem(c, centers=_dev(cen)[None], radii=_dev(np.ones(B))[None], k=_dev(ks), n_end=6, uin=uin, chunk=2)
+    x = np.array([[0.0, 0.0, 0.0], [9.0, 1.0, 0.5]])
+    u = calc.uscat(_dev(x.T)).cpu().numpy()           # (P, nb)
+    assert u.shape == (2, 5)
+    for s in (0, 3):
+        res, uo = _oracle_case("ba", cen, np.ones(B), ks[s], 6, 1.0, 1.0, 0.0, [1.0, 0.0, 0.0], x)
+        assert np.max(np.abs(u[:, s] - uo) / np.abs(uo)) < 1e-10
+
+
+def test_mfma_f64_rate_is_reported(lib):
+    l, L = lib
+    t = C.c_double()
+    L.check(l.biem_bench_mfma_f64(20000, C.byref(t), None))
+    print("v_mfma_f64_16x16x4_f64 issue-rate microbenchmark: %.1f TFLOP/s" % t.value)
+    assert 20.0 < t.value < 200.0

@@ -122,6 +122,14 @@ def test_translation_table_vs_quadrature_and_bruteforce():
         assert np.abs(proj - SR * j[deg][None, :]).max() < 1e-10 * np.abs(proj).max()
 
 
+def test_term_list_equals_dense_table_3d():
+    rng = np.random.default_rng(2)
+    t = rng.normal(size=3) * 2.5
+    a = O.translation_SR(O.tree("ba"), 9, 1.7, t)
+    b = O.translation_SR_ba_dense(9, 1.7, t)
+    assert np.abs(a - b).max() < 1e-13 * np.abs(b).max()
+
+
 def test_eta_independence_and_robin_residual():
     """u_scat does not depend on eta (column scaling cancels); Robin boundary residual -> 0 with n_end."""
     tr = O.tree("ba")
