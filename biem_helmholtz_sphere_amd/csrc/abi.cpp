@@ -175,7 +175,7 @@ SolveLayout make_layout(const biem_plan* p, int nb, int B, int chunk) {
   SolveLayout L;
   L.N = B * p->H;
   L.n_pad = lu_npad(L.N);
-  L.lda = L.n_pad + 2;              // one right-hand side column (+1 keeps rows 32-byte aligned)
+  L.lda = L.n_pad + 8;              // one right-hand side column; rows stay 128-byte aligned (8 complex128)
   L.sys_stride = (long long)L.n_pad * L.lda;
   if (chunk <= 0) {
     // resident matrices per chunk: as many as fit ~24 GiB, at most nb

@@ -13,6 +13,7 @@
 //   gemm         M[j+NB:, j+NB:] -= L21 * U12      zgemm on v_mfma_f64_16x16x4_f64 (4 real MFMAs per complex tile-step)
 // then a blocked back substitution with U.  All kernels are batched over systems (blockIdx.z / .y).
 #include "common.hpp"
+#include <cstdlib>
 
 namespace biem {
 
@@ -289,6 +290,218 @@ __global__ void __launch_bounds__(512) k_gemm(cplx* __restrict__ A, long long ld
 }
 
 // ---------------------------------------------------------------------------------------------
+// trailing update (product kernel) -- persistent zgemm on v_mfma_f64_4x4x4_4b_f64.
+//
+// MFMA form.  Measured on MI355X (tools/mfma_probe.hip, profiles/r01_mfma_f64_probe.txt): the 16x16x4 f64 MFMA
+// saturates at ~47-49 TFLOP/s (one per ~100 cycles per SIMD) at any occupancy, the 4-block 4x4x4 form issues every
+// ~17 cycles = 65-70 TFLOP/s.  The 4-block form multiplies A_blk (4x4) by B_blk (4x4) for blk = 0..3 (lane l:
+// i|j = l&3, blk = (l>>2)&3, k = l>>4; D: j = l&3, blk, i = l>>4; CBSZ/ABID are not honoured for f64:
+// profiles/r01_mfma_f64_4x4x4_layout.txt), so a 16x16 tile is built from 4 instructions whose A fragment holds the
+// SAME 4-row block in all four slots (an LDS broadcast read): accumulator g = rows 4g..4g+3 x 16 columns, i.e.
+// register g of the 16x16x4 result layout.  The f64 NEG bits (blgp bit 0 negates A) give acc = C - A*B directly.
+//
+// Memory schedule.  With K = NB the update is only 16 flop per byte of C traffic; a read-modify-write epilogue leaves
+// every wave ~60 % of its cycles in s_waitcnt (profiles/r01_gemm_pmc.txt) because all workgroups hit HBM together and
+// the MFMAs then idle.  Here each workgroup is persistent and streams: the C tile is loaded in slices during the
+// K-chunks (the accumulator of sub-tile c receives its C values in chunk c), the final stores stay in flight while
+// the next tile starts, and the first A/B chunk of the next tile is fetched during the last chunk of the current one.
+//
+// Tile order.  Tiles are numbered system-major, then bands of 8 tile-rows, then column-major inside a band, so 64
+// consecutive tiles form an 8 x 8 block sharing 8 A- and 8 B-panels.  Workgroup w takes tiles 64 (8 it + w%8) + w/8:
+// the 64 workgroups that share w%8 (one XCD under the observed round-robin placement; speed only) sweep one block.
+// ---------------------------------------------------------------------------------------------
+constexpr int BM2 = 64, BN2 = 128;
+
+struct TileGrid {
+  int ty_n, tx_n, per_sys, full_bands, ntiles;
+};
+
+__device__ inline void tile_decode(const TileGrid& tg, int t, int& s, int& ty, int& tx) {
+  s = t / tg.per_sys;
+  int r = t - s * tg.per_sys;
+  int fb = tg.full_bands * 8 * tg.tx_n;
+  if (r < fb) {
+    int band = r / (8 * tg.tx_n), rr = r - band * 8 * tg.tx_n;
+    tx = rr >> 3; ty = band * 8 + (rr & 7);
+  } else {
+    int rem = r - fb, h = tg.ty_n - tg.full_bands * 8;
+    tx = rem / h; ty = tg.full_bands * 8 + rem - tx * h;
+  }
+}
+
+template <int KD>
+__global__ void __launch_bounds__(256, 2) k_gemm_stream(cplx* __restrict__ A, long long lda, long long sys_stride,
+                                                         const cplx* __restrict__ Pw, long long ldp, long long p_stride,
+                                                         int n_pad, int n_cols, int j, TileGrid tg) {
+  constexpr int NCH = KD / KC;               // K-chunks per tile (8 or 16): even, so LDS buffer parity carries over tiles
+  constexpr int CSTEP = NCH / 8;             // a C slice is loaded every CSTEP chunks
+  __shared__ cplx sA[2][KC][BM2];
+  __shared__ cplx sB[2][KC][BN2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l3 = lane & 3, l15 = lane & 15, l4 = lane >> 4;
+  // tile sequence of this workgroup: blocks bi = w%8, w%8 + 8, ..; inside a block slots w/8, w/8 + nblk, .. (< 64)
+  const int w = blockIdx.x, slot0 = w >> 3, nblk = gridDim.x >> 3;
+  int bi = w & 7, sl = slot0 - nblk;
+  auto next_tile = [&]() -> int {
+    for (;;) {
+      sl += nblk;
+      if (sl >= 64) { sl = slot0; bi += 8; }
+      if (64 * bi >= tg.ntiles) return -1;
+      int t = 64 * bi + sl;
+      if (t < tg.ntiles) return t;
+    }
+  };
+  int t = next_tile();
+  if (t < 0) return;
+
+  // staging by LDS-DMA (global_load_lds_dwordx4): one wave-instruction = one contiguous 1 KiB k-row segment, so the
+  // LDS image [k][i] needs no VGPR round trip.  Out-of-range lanes are masked: their LDS slots keep stale values,
+  // which only reach accumulator rows/columns that are never stored.
+  const int ak = tid >> 6, ai = tid & 63;          // A: k-rows ak + 4 r, element ai
+  const int bk = tid >> 7, bq = tid & 127;         // B: k-rows bk + 2 r, element bq (wave-uniform segment (wave & 1) * 64)
+  const cplx zero = make_double2(0.0, 0.0);
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+  int cs, cty, ctx;
+  tile_decode(tg, t, cs, cty, ctx);
+  auto stage = [&](int s_, int ty_, int tx_, int kc, int buf) {
+    const cplx* Ps = Pw + (size_t)s_ * p_stride;
+    const cplx* As = A + (size_t)s_ * sys_stride;
+    const int r0 = j + KD + ty_ * BM2, c0 = j + KD + tx_ * BN2;
+    if (r0 + ai < n_pad) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ps + (size_t)(kc + ak + 4 * r) * ldp + r0 + ai),
+                                         (lds_ptr_t)(&sA[buf][ak + 4 * r][0]), 16, 0, 0);
+    }
+    if (c0 + bq < n_cols) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(As + (size_t)(j + kc + bk + 2 * r) * lda + c0 + bq),
+                                         (lds_ptr_t)(&sB[buf][bk + 2 * r][(wave & 1) * 64]), 16, 0, 0);
+    }
+  };
+
+  double accR[2][4][4], accI[2][4][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { accR[a][b][g] = 0.0; accI[a][b][g] = 0.0; }
+
+  stage(cs, cty, ctx, 0, 0);
+  __syncthreads();
+
+  for (;;) {
+    cplx* Cs = A + (size_t)cs * sys_stride;
+    const int row0 = j + KD + cty * BM2, col0 = j + KD + ctx * BN2;
+    int tn = -1, ns = 0, nty = 0, ntx = 0;
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+      const int buf = c & 1;
+      // next chunk (or the first chunk of the next tile) lands in the other buffer while this one is multiplied;
+      // the barrier at the end of the chunk waits for it (vmcnt(0) + s_barrier)
+      if (c + 1 < NCH) {
+        stage(cs, cty, ctx, (c + 1) * KC, buf ^ 1);
+      } else {
+        tn = next_tile();
+        if (tn >= 0) { tile_decode(tg, tn, ns, nty, ntx); stage(ns, nty, ntx, 0, buf ^ 1); }
+      }
+      // C slice of sub-tile number c / CSTEP = (tm, tn): issued now, consumed after this chunk's MFMAs
+      cplx cl[4];
+      const bool cslice = (c % CSTEP) == 0;
+      const int cq = c / CSTEP;
+      if (cslice) {
+        const int col = col0 + wn * 64 + (cq & 3) * 16 + l15;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = row0 + wm * 32 + (cq >> 2) * 16 + 4 * g + l4;
+          cl[g] = (col < n_cols && row < n_pad) ? Cs[(size_t)row * lda + col] : zero;
+        }
+      }
+#pragma unroll
+      for (int k4 = 0; k4 < KC / 4; ++k4) {
+        const int kk = k4 * 4 + l4;
+        cplx b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = sB[buf][kk][wn * 64 + q * 16 + l15];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+          cplx a[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) a[g] = sA[buf][kk][wm * 32 + tm * 16 + 4 * g + l3];
+          // acc = C - A*B:  Re: -(ArBr) + AiBi,  Im: -(ArBi) - (AiBr); dependent MFMAs are 16 instructions apart
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) accR[tm][q][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[g].x, b[q].x, accR[tm][q][g], 0, 0, 1);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) accI[tm][q][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[g].x, b[q].y, accI[tm][q][g], 0, 0, 1);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) accR[tm][q][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[g].y, b[q].y, accR[tm][q][g], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) accI[tm][q][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[g].y, b[q].x, accI[tm][q][g], 0, 0, 1);
+        }
+      }
+      if (cslice) {
+#define BIEM_CADD(TM, TN) _Pragma("unroll") for (int g = 0; g < 4; ++g) { accR[TM][TN][g] += cl[g].x; accI[TM][TN][g] += cl[g].y; }
+        switch (cq) {   // wave-uniform: the accumulator index has to be a compile-time constant
+          case 0: BIEM_CADD(0, 0) break;
+          case 1: BIEM_CADD(0, 1) break;
+          case 2: BIEM_CADD(0, 2) break;
+          case 3: BIEM_CADD(0, 3) break;
+          case 4: BIEM_CADD(1, 0) break;
+          case 5: BIEM_CADD(1, 1) break;
+          case 6: BIEM_CADD(1, 2) break;
+          default: BIEM_CADD(1, 3) break;
+        }
+#undef BIEM_CADD
+      }
+      __syncthreads();
+    }
+    // results: plain stores, left in flight while the next tile starts
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = col0 + wn * 64 + q * 16 + l15;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = row0 + wm * 32 + tm * 16 + 4 * g + l4;
+          if (col < n_cols && row < n_pad) Cs[(size_t)row * lda + col] = make_double2(accR[tm][q][g], accI[tm][q][g]);
+          accR[tm][q][g] = 0.0; accI[tm][q][g] = 0.0;
+        }
+      }
+    }
+    if (tn < 0) break;
+    cs = ns; cty = nty; ctx = ntx;
+  }
+}
+
+static void launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, long long sys_stride, const cplx* Pw, long long ldp,
+                               long long p_stride, int n_pad, int n_cols, int j, int kd) {
+  const int rrows = n_pad - (j + kd), rcols = n_cols - (j + kd);
+  TileGrid tg;
+  tg.ty_n = (rrows + BM2 - 1) / BM2; tg.tx_n = (rcols + BN2 - 1) / BN2;
+  tg.per_sys = tg.ty_n * tg.tx_n; tg.full_bands = tg.ty_n / 8; tg.ntiles = tg.per_sys * nb;
+  int want = (tg.ntiles + 7) / 8 * 8;          // one workgroup per tile, capped at 2 per CU, multiple of 8
+  int grid = want < 512 ? want : 512;
+  if (kd == 64)
+    hipLaunchKernelGGL(k_gemm_stream<64>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, n_pad, n_cols, j, tg);
+  else
+    hipLaunchKernelGGL(k_gemm_stream<128>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, n_pad, n_cols, j, tg);
+}
+
+// ---------------------------------------------------------------------------------------------
 // back substitution with U (row-major), block size BS
 // ---------------------------------------------------------------------------------------------
 // diagonal block: x = U[jr:jr+BS, jr:jr+BS]^{-1} y, one 64-thread workgroup per (system, rhs)
@@ -343,6 +556,7 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
   cplx* Pw = (cplx*)d_work;
   const long long ldp = ldp_of(n_pad), p_stride = (long long)NB * ldp;
   const int n_cols = n_pad + nrhs;
+  static const int gemm_variant = getenv("BIEM_GEMM_V1") ? 1 : 2;   // A/B switch for the design notes; v2 is the product
   hipLaunchKernelGGL(k_zero_int, dim3((nb + 63) / 64), dim3(64), 0, st, d_info, nb);
   for (int j = 0; j < n_pad; j += NB) {
     const int rows = n_pad - j;
@@ -365,8 +579,11 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
       const int rrows = n_pad - (j + NB);
       if (rrows > 0) {
         ProfScope ps(PK_GEMM, st, 8.0 * (double)nb * rrows * (double)rcols * NB);
-        hipLaunchKernelGGL(k_gemm, dim3((rcols + BN - 1) / BN, (rrows + BM - 1) / BM, nb), dim3(512), 0, st, A, lda, sys_stride, Pw,
-                           ldp, p_stride, n_pad, n_cols, j);
+        if (gemm_variant == 1)
+          hipLaunchKernelGGL(k_gemm, dim3((rcols + BN - 1) / BN, (rrows + BM - 1) / BM, nb), dim3(512), 0, st, A, lda, sys_stride,
+                             Pw, ldp, p_stride, n_pad, n_cols, j);
+        else
+          launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, n_pad, n_cols, j, NB);
       }
     }
   }
