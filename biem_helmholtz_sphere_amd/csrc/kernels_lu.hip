@@ -70,66 +70,111 @@ __global__ void __launch_bounds__(256) k_panel_store(cplx* __restrict__ A, long 
 }
 
 // ---------------------------------------------------------------------------------------------
-// panel factorisation: unblocked right-looking LU with partial pivoting on the column-major panel.
-// Pivot = max |re| + |im| (LAPACK izamax's cabs1), ties -> smallest row.  One 1024-thread workgroup per system.
+// panel factorisation: LU with partial pivoting of the column-major panel, blocked in strips of PW columns.
+//   strip  : unblocked right-looking elimination confined to the strip's PW columns (pivot = max |re| + |im|,
+//            LAPACK izamax's cabs1, ties -> smallest row; the row interchange is applied to all NB columns)
+//   right  : U_strip,right = L_strip^{-1} P[strip rows, right columns], then one rank-PW update of the rows below
+// The unblocked form swept the whole remaining panel once per column (NB^2/2 column passes through L2: 2.2 ms per
+// 6400 x 64 panel, profiles/r01_v1_kernel_stats_cfg3_8sys.csv); the strips cut that traffic ~4x.
+// One 1024-thread workgroup per system.
 // ---------------------------------------------------------------------------------------------
+constexpr int PW = 8;
+
 __global__ void __launch_bounds__(1024) k_panel_factor(cplx* __restrict__ Pw, long long ldp, long long p_stride, int n_pad, int j,
                                                         int* __restrict__ ipiv, int* __restrict__ info) {
   __shared__ double sval[16];
   __shared__ int sidx[16];
-  __shared__ cplx sU[NB];
+  __shared__ cplx sU[PW];          // current pivot row restricted to the strip
+  __shared__ cplx sL[PW][PW];      // unit-lower strip triangle
+  __shared__ cplx sUr[PW][NB];     // U rows of the strip for the right columns
   __shared__ int sPiv;
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   cplx* Ps = Pw + (size_t)s * p_stride;
-  for (int c = 0; c < NB; ++c) {
-    cplx* col = Ps + (size_t)c * ldp;
-    const int r0 = j + c;
-    double best = -1.0;
-    int bi = 0x7fffffff;
-    for (int i = r0 + tid; i < n_pad; i += 1024) {
-      cplx v = col[i];
-      double a = fabs(v.x) + fabs(v.y);
-      if (a > best) { best = a; bi = i; }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-      double ob = __shfl_down(best, o, 64);
-      int oi = __shfl_down(bi, o, 64);
-      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
-    if (lane == 0) { sval[wave] = best; sidx[wave] = bi; }
-    __syncthreads();
-    if (tid == 0) {
-      double b = sval[0]; int ix = sidx[0];
-      for (int w = 1; w < 16; ++w) if (sval[w] > b || (sval[w] == b && sidx[w] < ix)) { b = sval[w]; ix = sidx[w]; }
-      if (ix == 0x7fffffff) ix = r0;   // all-NaN column: keep the diagonal
-      sPiv = ix;
-      ipiv[(size_t)s * n_pad + r0] = ix;
-    }
-    __syncthreads();
-    const int p = sPiv;
-    if (tid < NB) {
-      cplx a = Ps[(size_t)tid * ldp + r0];
-      if (p != r0) {
-        cplx b = Ps[(size_t)tid * ldp + p];
-        Ps[(size_t)tid * ldp + p] = a;
-        Ps[(size_t)tid * ldp + r0] = b;
-        a = b;
+  for (int c0 = 0; c0 < NB; c0 += PW) {
+    for (int c = c0; c < c0 + PW; ++c) {
+      cplx* col = Ps + (size_t)c * ldp;
+      const int r0 = j + c;
+      double best = -1.0;
+      int bi = 0x7fffffff;
+      for (int i = r0 + tid; i < n_pad; i += 1024) {
+        cplx v = col[i];
+        double a = fabs(v.x) + fabs(v.y);
+        if (a > best) { best = a; bi = i; }
       }
-      sU[tid] = a;   // row r0 of the panel after the interchange
+      for (int o = 32; o > 0; o >>= 1) {
+        double ob = __shfl_down(best, o, 64);
+        int oi = __shfl_down(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      if (lane == 0) { sval[wave] = best; sidx[wave] = bi; }
+      __syncthreads();
+      if (tid == 0) {
+        double b = sval[0]; int ix = sidx[0];
+        for (int w = 1; w < 16; ++w) if (sval[w] > b || (sval[w] == b && sidx[w] < ix)) { b = sval[w]; ix = sidx[w]; }
+        if (ix == 0x7fffffff) ix = r0;   // all-NaN column: keep the diagonal
+        sPiv = ix;
+        ipiv[(size_t)s * n_pad + r0] = ix;
+      }
+      __syncthreads();
+      const int p = sPiv;
+      if (tid < NB) {
+        cplx a = Ps[(size_t)tid * ldp + r0];
+        if (p != r0) {
+          cplx b = Ps[(size_t)tid * ldp + p];
+          Ps[(size_t)tid * ldp + p] = a;
+          Ps[(size_t)tid * ldp + r0] = b;
+          a = b;
+        }
+        if (tid >= c0 && tid < c0 + PW) sU[tid - c0] = a;   // row r0 after the interchange, strip columns
+      }
+      __syncthreads();
+      const cplx piv = sU[c - c0];
+      if (piv.x == 0.0 && piv.y == 0.0) {
+        if (tid == 0 && info[s] == 0) info[s] = r0 + 1;
+        continue;   // uniform: exactly singular column, nothing to eliminate
+      }
+      const cplx rinv = crecip(piv);
+      for (int i = r0 + 1 + tid; i < n_pad; i += 1024) {
+        cplx l = cmul(col[i], rinv);
+        col[i] = l;
+        for (int cc = c + 1; cc < c0 + PW; ++cc) {
+          cplx* q = Ps + (size_t)cc * ldp + i;
+          *q = cfnma(l, sU[cc - c0], *q);
+        }
+      }
+      __syncthreads();
+    }
+    const int nright = NB - (c0 + PW);
+    if (nright <= 0) break;
+    const int rs = j + c0;               // first row of the strip
+    if (tid < PW * PW) {
+      int q = tid / PW, q2 = tid % PW;   // L[q][q2], q2 < q
+      sL[q][q2] = (q2 < q) ? Ps[(size_t)(c0 + q2) * ldp + rs + q] : make_double2(0.0, 0.0);
     }
     __syncthreads();
-    const cplx piv = sU[c];
-    if (piv.x == 0.0 && piv.y == 0.0) {
-      if (tid == 0 && info[s] == 0) info[s] = r0 + 1;
-      continue;   // uniform: exactly singular column, nothing to eliminate
+    if (tid < nright) {
+      cplx* colr = Ps + (size_t)(c0 + PW + tid) * ldp + rs;
+      cplx x[PW];
+#pragma unroll
+      for (int q = 0; q < PW; ++q) x[q] = colr[q];
+#pragma unroll
+      for (int q = 1; q < PW; ++q)
+#pragma unroll
+        for (int q2 = 0; q2 < q; ++q2) x[q] = cfnma(sL[q][q2], x[q2], x[q]);
+#pragma unroll
+      for (int q = 0; q < PW; ++q) { colr[q] = x[q]; sUr[q][tid] = x[q]; }
     }
-    const cplx rinv = crecip(piv);
-    for (int i = r0 + 1 + tid; i < n_pad; i += 1024) {
-      cplx l = cmul(col[i], rinv);
-      col[i] = l;
-      for (int cc = c + 1; cc < NB; ++cc) {
-        cplx* q = Ps + (size_t)cc * ldp + i;
-        *q = cfnma(l, sU[cc], *q);
+    __syncthreads();
+    for (int i = rs + PW + tid; i < n_pad; i += 1024) {
+      cplx l[PW];
+#pragma unroll
+      for (int q = 0; q < PW; ++q) l[q] = Ps[(size_t)(c0 + q) * ldp + i];
+      for (int t = 0; t < nright; ++t) {
+        cplx* q_ = Ps + (size_t)(c0 + PW + t) * ldp + i;
+        cplx v = *q_;
+#pragma unroll
+        for (int q = 0; q < PW; ++q) v = cfnma(l[q], sUr[q][t], v);
+        *q_ = v;
       }
     }
     __syncthreads();
