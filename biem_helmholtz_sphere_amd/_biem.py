@@ -380,17 +380,56 @@ class BIEMResultCalculator:
 # --------------------------------------------------------------------------------------
 # input checking (reference :240-326; error and warning texts are part of the API)
 # --------------------------------------------------------------------------------------
-def _check_biem_inputs(c, centers, radii, k, eta, alpha, beta):
+def _shape(a: Any) -> Tuple[int, ...]:
+    return tuple(a.shape) if isinstance(a, (torch.Tensor, np.ndarray)) else tuple(np.shape(a))
+
+
+def _validate_biem_inputs(c, centers, radii, k, eta, alpha, beta) -> Tuple[int, ...]:
+    """Shape / dtype checks of reference :240-326 on metadata only (no device needed); returns the batch shape."""
     for nm, a in (("centers", centers), ("radii", radii), ("k", k)):
         if not isinstance(a, (torch.Tensor, np.ndarray)):
             raise TypeError(f"{nm} must be an array (torch.Tensor or numpy.ndarray), got {type(a).__name__}")
-    origin, dev = _origin_of(centers, radii, k, eta, alpha, beta)
-    f64 = torch.float64
-    # check decoupling parameter
     if eta is not None and _is_complex(eta):
         raise ValueError("The decoupling parameter must be real.")
     if _is_complex(k):
         raise NotImplementedError("complex wavenumbers are not built yet in the MI355X kernels (SURVEY 8(f) item 3)")
+    ks, cs, rs = _shape(k), _shape(centers), _shape(radii)
+    es = (1,) * len(ks) if eta is None else _shape(eta)
+    als = _shape(alpha) or (1,) * (len(ks) + 1)
+    bes = _shape(beta) or (1,) * (len(ks) + 1)
+    if len({len(ks), len(es), len(cs) - 2, len(rs) - 1}) != 1:
+        raise ValueError(
+            f"k.ndim={len(ks)}, eta.ndim={len(es)}, centers.ndim - 2={len(cs) - 2}, radii.ndim -1={len(rs) - 1}are not the same."
+        )
+    if len(als) != len(ks) + 1 or len(bes) != len(ks) + 1:
+        raise ValueError(f"alpha and beta must be scalars or arrays of shape (..., B) with {len(ks) + 1} axes")
+    try:
+        batch = np.broadcast_shapes(ks, es, cs[:-2], rs[:-1], als[:-1], bes[:-1])
+    except ValueError as e:
+        raise ValueError(
+            "Shapes of k, eta and "
+            "centers.shape[:-2], radii.shape[:-1] "
+            "are not broadcastable\n"
+            f"tuple(k.shape)={ks}\ntuple(eta.shape)={es}\ntuple(centers.shape)={cs}\ntuple(radii.shape)={rs}\n"
+            f"tuple(alpha.shape)={als}\ntuple(beta.shape)={bes}"
+        ) from e
+    try:
+        np.broadcast_shapes(cs[:-1], rs, als, bes)
+    except ValueError as e:
+        raise ValueError(
+            "centers.shape[:-1] and radii.shape "
+            "are not broadcastable\n"
+            f"tuple(centers.shape)={cs}\ntuple(radii.shape)={rs}\ntuple(alpha.shape)={als}\ntuple(beta.shape)={bes}"
+        ) from e
+    if cs[-1] != c.c_ndim:
+        raise ValueError(f"The last dimension of centers must be c.c_ndim={c.c_ndim}, but got {cs[-1]}")
+    return tuple(batch)
+
+
+def _check_biem_inputs(c, centers, radii, k, eta, alpha, beta):
+    batch = _validate_biem_inputs(c, centers, radii, k, eta, alpha, beta)
+    origin, dev = _origin_of(centers, radii, k, eta, alpha, beta)
+    f64 = torch.float64
     centers_t = _to_dev(centers, dev, f64)
     radii_t = _to_dev(radii, dev, f64)
     k_t = _to_dev(k, dev, f64)
@@ -404,7 +443,6 @@ def _check_biem_inputs(c, centers, radii, k, eta, alpha, beta):
     beta_t = _to_dev(beta, dev, torch.complex128)
     if beta_t.ndim == 0:
         beta_t = beta_t[(None,) * (k_t.ndim + 1)]
-
     if bool(torch.any(eta_t == 0)):
         warnings.warn(
             "The solution may be incorrect"
@@ -416,38 +454,6 @@ def _check_biem_inputs(c, centers, radii, k, eta, alpha, beta):
         )
     if bool(torch.any(eta_t * k_t < 0)):
         warnings.warn("The solution may be incorrectif not (Im k >= 0 and eta Re k >= 0).", UserWarning, stacklevel=3)
-
-    # check if broadcastable
-    if len({k_t.ndim, eta_t.ndim, centers_t.ndim - 2, radii_t.ndim - 1}) != 1:
-        raise ValueError(
-            f"k.ndim={k_t.ndim}, eta.ndim={eta_t.ndim}, centers.ndim - 2={centers_t.ndim - 2}, "
-            f"radii.ndim -1={radii_t.ndim - 1}are not the same."
-        )
-    if alpha_t.ndim != k_t.ndim + 1 or beta_t.ndim != k_t.ndim + 1:
-        raise ValueError(f"alpha and beta must be scalars or arrays of shape (..., B) with {k_t.ndim + 1} axes")
-    try:
-        batch = np.broadcast_shapes(
-            tuple(k_t.shape), tuple(eta_t.shape), tuple(centers_t.shape[:-2]), tuple(radii_t.shape[:-1]),
-            tuple(alpha_t.shape[:-1]), tuple(beta_t.shape[:-1]),
-        )
-    except ValueError as e:
-        raise ValueError(
-            "Shapes of k, eta and "
-            "centers.shape[:-2], radii.shape[:-1] "
-            "are not broadcastable\n"
-            f"{tuple(k_t.shape)=}\n{tuple(eta_t.shape)=}\n{tuple(centers_t.shape)=}\n{tuple(radii_t.shape)=}\n"
-            f"{tuple(alpha_t.shape)=}\n{tuple(beta_t.shape)=}".replace("_t.shape", ".shape")
-        ) from e
-    try:
-        np.broadcast_shapes(tuple(centers_t.shape[:-1]), tuple(radii_t.shape), tuple(alpha_t.shape), tuple(beta_t.shape))
-    except ValueError as e:
-        raise ValueError(
-            "centers.shape[:-1] and radii.shape "
-            "are not broadcastable\n"
-            f"{tuple(centers_t.shape)=}\n{tuple(radii_t.shape)=}\n{tuple(alpha_t.shape)=}\n{tuple(beta_t.shape)=}".replace("_t.shape", ".shape")
-        ) from e
-    if centers_t.shape[-1] != c.c_ndim:
-        raise ValueError(f"The last dimension of centers must be c.c_ndim={c.c_ndim}, but got {centers_t.shape[-1]}")
     return origin, dev, batch, centers_t, radii_t, k_t, eta_t, alpha_t, beta_t
 
 
