@@ -28,7 +28,7 @@ static inline long long ldp_of(int n_pad) { return (long long)n_pad; }
 
 size_t lu_workspace_bytes(int nb, int n_pad, int nrhs) {
   (void)nrhs;
-  return (size_t)nb * NB * (size_t)ldp_of(n_pad) * sizeof(cplx);
+  return (size_t)nb * 2 * NB * (size_t)ldp_of(n_pad) * sizeof(cplx);   // two 64-column panels (one K = 128 block)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -359,6 +359,8 @@ constexpr int BM2 = 64, BN2 = 128;
 
 struct TileGrid {
   int ty_n, tx_n, per_sys, full_bands, ntiles;
+  int row_begin, row_end, col_begin, col_end;   // C region updated by this launch
+  int brow;                                     // first row of the B operand (U12 rows brow .. brow + K)
 };
 
 __device__ inline void tile_decode(const TileGrid& tg, int t, int& s, int& ty, int& tx) {
@@ -377,7 +379,8 @@ __device__ inline void tile_decode(const TileGrid& tg, int t, int& s, int& ty, i
 template <int KD>
 __global__ void __launch_bounds__(256, 2) k_gemm_stream(cplx* __restrict__ A, long long lda, long long sys_stride,
                                                          const cplx* __restrict__ Pw, long long ldp, long long p_stride,
-                                                         int n_pad, int n_cols, int j, TileGrid tg) {
+                                                         TileGrid tg) {
+  const int n_pad = tg.row_end, n_cols = tg.col_end;
   constexpr int NCH = KD / KC;               // K-chunks per tile (8 or 16): even, so LDS buffer parity carries over tiles
   constexpr int CSTEP = NCH / 8;             // a C slice is loaded every CSTEP chunks
   __shared__ cplx sA[2][KC][BM2];
@@ -414,7 +417,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_stream(cplx* __restrict__ A, lo
   auto stage = [&](int s_, int ty_, int tx_, int kc, int buf) {
     const cplx* Ps = Pw + (size_t)s_ * p_stride;
     const cplx* As = A + (size_t)s_ * sys_stride;
-    const int r0 = j + KD + ty_ * BM2, c0 = j + KD + tx_ * BN2;
+    const int r0 = tg.row_begin + ty_ * BM2, c0 = tg.col_begin + tx_ * BN2;
     if (r0 + ai < n_pad) {
 #pragma unroll
       for (int r = 0; r < 2; ++r)
@@ -424,7 +427,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_stream(cplx* __restrict__ A, lo
     if (c0 + bq < n_cols) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(As + (size_t)(j + kc + bk + 2 * r) * lda + c0 + bq),
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(As + (size_t)(tg.brow + kc + bk + 2 * r) * lda + c0 + bq),
                                          (lds_ptr_t)(&sB[buf][bk + 2 * r][(wave & 1) * 64]), 16, 0, 0);
     }
   };
@@ -442,7 +445,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_stream(cplx* __restrict__ A, lo
 
   for (;;) {
     cplx* Cs = A + (size_t)cs * sys_stride;
-    const int row0 = j + KD + cty * BM2, col0 = j + KD + ctx * BN2;
+    const int row0 = tg.row_begin + cty * BM2, col0 = tg.col_begin + ctx * BN2;
     int tn = -1, ns = 0, nty = 0, ntx = 0;
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
@@ -532,18 +535,33 @@ __global__ void __launch_bounds__(256, 2) k_gemm_stream(cplx* __restrict__ A, lo
   }
 }
 
+// C[row_begin:row_end, col_begin:col_end] -= P[0:kd]^T (rows of the region) * M[brow:brow+kd, cols of the region]
 static void launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, long long sys_stride, const cplx* Pw, long long ldp,
-                               long long p_stride, int n_pad, int n_cols, int j, int kd) {
-  const int rrows = n_pad - (j + kd), rcols = n_cols - (j + kd);
+                               long long p_stride, int row_begin, int row_end, int col_begin, int col_end, int brow, int kd) {
+  const int rrows = row_end - row_begin, rcols = col_end - col_begin;
+  if (rrows <= 0 || rcols <= 0) return;
   TileGrid tg;
   tg.ty_n = (rrows + BM2 - 1) / BM2; tg.tx_n = (rcols + BN2 - 1) / BN2;
   tg.per_sys = tg.ty_n * tg.tx_n; tg.full_bands = tg.ty_n / 8; tg.ntiles = tg.per_sys * nb;
+  tg.row_begin = row_begin; tg.row_end = row_end; tg.col_begin = col_begin; tg.col_end = col_end; tg.brow = brow;
   int want = (tg.ntiles + 7) / 8 * 8;          // one workgroup per tile, capped at 2 per CU, multiple of 8
   int grid = want < 512 ? want : 512;
+  ProfScope ps(PK_GEMM, st, 8.0 * (double)nb * rrows * (double)rcols * kd);
   if (kd == 64)
-    hipLaunchKernelGGL(k_gemm_stream<64>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, n_pad, n_cols, j, tg);
+    hipLaunchKernelGGL(k_gemm_stream<64>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
   else
-    hipLaunchKernelGGL(k_gemm_stream<128>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, n_pad, n_cols, j, tg);
+    hipLaunchKernelGGL(k_gemm_stream<128>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
+}
+
+// apply the row interchanges of the second panel of a block to the stored multipliers of the first (P columns 0..NB-1)
+__global__ void __launch_bounds__(64) k_swap_p(cplx* __restrict__ Pw, long long ldp, long long p_stride, int n_pad, int j,
+                                                const int* __restrict__ ipiv) {
+  const int s = blockIdx.x, c = threadIdx.x;
+  cplx* col = Pw + (size_t)s * p_stride + (size_t)c * ldp;
+  for (int q = 0; q < NB; ++q) {
+    int p = ipiv[(size_t)s * n_pad + j + q];
+    if (p != j + q) { cplx a = col[j + q]; col[j + q] = col[p]; col[p] = a; }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -599,37 +617,62 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
   if (work_bytes < lu_workspace_bytes(nb, n_pad, nrhs)) { set_error("biem_lu: workspace too small"); return BIEM_ERR_ARG; }
   cplx* A = (cplx*)d_A;
   cplx* Pw = (cplx*)d_work;
-  const long long ldp = ldp_of(n_pad), p_stride = (long long)NB * ldp;
+  const long long ldp = ldp_of(n_pad), p_stride = 2LL * NB * ldp;
   const int n_cols = n_pad + nrhs;
   static const int gemm_variant = getenv("BIEM_GEMM_V1") ? 1 : 2;   // A/B switch for the design notes; v2 is the product
   hipLaunchKernelGGL(k_zero_int, dim3((nb + 63) / 64), dim3(64), 0, st, d_info, nb);
-  for (int j = 0; j < n_pad; j += NB) {
+
+  // factor the 64-column panel at column j, multipliers into P columns [pc, pc + NB)
+  auto panel = [&](int j, int pc) {
+    cplx* Pj = Pw + (size_t)pc * ldp;
     const int rows = n_pad - j;
-    {
-      ProfScope ps(PK_PANEL, st, 4.0 * (double)nb * rows * NB * NB);
-      hipLaunchKernelGGL(k_panel_load, dim3((rows + TR - 1) / TR, nb), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, n_pad, j);
-      hipLaunchKernelGGL(k_panel_factor, dim3(nb), dim3(1024), 0, st, Pw, ldp, p_stride, n_pad, j, d_ipiv, d_info);
-      hipLaunchKernelGGL(k_panel_store, dim3((rows + TR - 1) / TR, nb), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, n_pad, j);
-    }
-    const int rcols = n_cols - (j + NB);   // columns right of the panel (>= nrhs)
-    if (rcols > 0) {
-      {
-        ProfScope ps(PK_SWAP, st, 64.0 * (double)nb * NB * rcols);
-        hipLaunchKernelGGL(k_swap, dim3((rcols + 255) / 256, nb), dim3(256), 0, st, A, lda, sys_stride, n_pad, n_cols, j, d_ipiv, 0);
-      }
-      {
-        ProfScope ps(PK_TRSM, st, 4.0 * (double)nb * NB * NB * rcols);
-        hipLaunchKernelGGL(k_trsm, dim3((rcols + TC - 1) / TC, nb), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, n_cols, j);
-      }
-      const int rrows = n_pad - (j + NB);
-      if (rrows > 0) {
+    ProfScope ps(PK_PANEL, st, 4.0 * (double)nb * rows * NB * NB);
+    hipLaunchKernelGGL(k_panel_load, dim3((rows + TR - 1) / TR, nb), dim3(256), 0, st, A, lda, sys_stride, Pj, ldp, p_stride, n_pad, j);
+    hipLaunchKernelGGL(k_panel_factor, dim3(nb), dim3(1024), 0, st, Pj, ldp, p_stride, n_pad, j, d_ipiv, d_info);
+    hipLaunchKernelGGL(k_panel_store, dim3((rows + TR - 1) / TR, nb), dim3(256), 0, st, A, lda, sys_stride, Pj, ldp, p_stride, n_pad, j);
+    if (pc > 0) hipLaunchKernelGGL(k_swap_p, dim3(nb), dim3(64), 0, st, Pw, ldp, p_stride, n_pad, j, d_ipiv);
+  };
+  // the panel's row interchanges on the columns right of it
+  auto swap_right = [&](int j) {
+    const int rcols = n_cols - (j + NB);
+    if (rcols <= 0) return;
+    ProfScope ps(PK_SWAP, st, 64.0 * (double)nb * NB * rcols);
+    hipLaunchKernelGGL(k_swap, dim3((rcols + 255) / 256, nb), dim3(256), 0, st, A, lda, sys_stride, n_pad, n_cols, j, d_ipiv, 0);
+  };
+  // U row block: M[j:j+NB, j+NB:] <- L11^{-1} M[j:j+NB, j+NB:]
+  auto trsm = [&](int j, int pc) {
+    const int rcols = n_cols - (j + NB);
+    if (rcols <= 0) return;
+    ProfScope ps(PK_TRSM, st, 4.0 * (double)nb * NB * NB * rcols);
+    hipLaunchKernelGGL(k_trsm, dim3((rcols + TC - 1) / TC, nb), dim3(256), 0, st, A, lda, sys_stride, Pw + (size_t)pc * ldp, ldp,
+                       p_stride, n_cols, j);
+  };
+
+  if (gemm_variant == 1) {
+    // v1 reference schedule: K = 64 steps, 16x16x4 MFMA with a read-modify-write epilogue
+    for (int j = 0; j < n_pad; j += NB) {
+      panel(j, 0); swap_right(j); trsm(j, 0);
+      const int rcols = n_cols - (j + NB), rrows = n_pad - (j + NB);
+      if (rcols > 0 && rrows > 0) {
         ProfScope ps(PK_GEMM, st, 8.0 * (double)nb * rrows * (double)rcols * NB);
-        if (gemm_variant == 1)
-          hipLaunchKernelGGL(k_gemm, dim3((rcols + BN - 1) / BN, (rrows + BM - 1) / BM, nb), dim3(512), 0, st, A, lda, sys_stride,
-                             Pw, ldp, p_stride, n_pad, n_cols, j);
-        else
-          launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, n_pad, n_cols, j, NB);
+        hipLaunchKernelGGL(k_gemm, dim3((rcols + BN - 1) / BN, (rrows + BM - 1) / BM, nb), dim3(512), 0, st, A, lda, sys_stride, Pw,
+                           ldp, p_stride, n_pad, n_cols, j);
       }
+    }
+  } else {
+    // two-level schedule, block = two 64-column panels a (at J) and b (at J + 64):
+    //   a: factor, interchanges, U row block; its K = 64 update goes only to the 64 columns panel b consists of
+    //   b: factor, interchanges (also on a's stored multipliers); only now - with the rows in their final order - a's
+    //      update of the 64 rows of b's U block, then b's U row block
+    //   one K = 128 update of everything below and right of the block with [L21a | L21b] x [U12a ; U12b]
+    for (int J = 0; J < n_pad; J += 2 * NB) {
+      panel(J, 0); swap_right(J); trsm(J, 0);
+      if (J + NB >= n_pad) break;                        // odd tail: nothing below the panel, forward elimination done
+      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + NB, n_pad, J + NB, J + 2 * NB, J, NB);
+      panel(J + NB, NB); swap_right(J + NB);
+      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + NB, J + 2 * NB, J + 2 * NB, n_cols, J, NB);
+      trsm(J + NB, NB);
+      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 2 * NB, n_pad, J + 2 * NB, n_cols, J, 2 * NB);
     }
   }
   BIEM_LAUNCHCHK();
