@@ -153,56 +153,81 @@ __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int
 //   off-diagonal:  A = R_b[n(h)] * Cc_{b'}[n(h')] * sum_p coef[p] T_{bb'}[tidx[p]]        ((S|R)^T, _biem.py:769)
 //   diagonal    :  A = delta_{hh'} * Dg_b[n(h)]
 // with (R, Cc, Dg) = (gj, blc, gh*blc) for the reference scaling (_biem.py:745-789) and (gj, 1/gh, 1) for the
-// equilibrated system the LU factors.  One block per (row chunk, pair, system); the pair's T table sits in LDS;
-// consecutive lanes own consecutive columns h' -> 16-byte coalesced stores, each element written once.
+// equilibrated system the LU factors.
+// One 1024-thread workgroup per (entry chunk, ball b, system).  The chunk's slice of the term list (8-byte coefficient +
+// 2-byte table index per term) and its row pointers are loaded into LDS ONCE and reused for all partner balls b'; per
+// partner only its pair table T (H2 complex) and column factors are staged.  Every thread keeps two independent entries
+// in flight (the per-term chain idx -> T -> fma is LDS-latency bound).  The first version (256 threads, term list from
+// L2 for every pair) ran at 487 GB/s (profiles/r01_bench_cfg3_32sys.json).  Consecutive lanes own consecutive columns
+// h': 16-byte coalesced stores, every matrix element written exactly once.
 // ---------------------------------------------------------------------------------------------
-template <int ROWS>
-__global__ void __launch_bounds__(256) k_fill(int H, int H2, int n_end, int B, const int* __restrict__ deg,
-                                               const uint32_t* __restrict__ ptr, const double* __restrict__ coef,
-                                               const int32_t* __restrict__ tidx, const cplx* __restrict__ T,
-                                               const cplx* __restrict__ tab, int scaling, cplx* __restrict__ A, long long lda,
-                                               long long sys_stride) {
-  extern __shared__ cplx sT[];   // [H2] + column factors [H]
-  cplx* sC = sT + H2;
-  int pair = blockIdx.y, s = blockIdx.z;
-  int b = pair / B, bp = pair % B;
-  int h0 = blockIdx.x * ROWS;
-  cplx* Ab = A + (size_t)s * sys_stride + ((size_t)b * H) * lda + (size_t)bp * H;
+constexpr int FILL_THREADS = 1024;
+
+__global__ void __launch_bounds__(FILL_THREADS) k_fill(int H, int H2, int n_end, int B, const int* __restrict__ deg,
+                                                        const int* __restrict__ chunk_ent, int chunk_terms_max, int chunk_ents_max,
+                                                        const uint32_t* __restrict__ ptr, const double* __restrict__ coef,
+                                                        const uint16_t* __restrict__ tidx, const cplx* __restrict__ T,
+                                                        const cplx* __restrict__ tab, int scaling, cplx* __restrict__ A,
+                                                        long long lda, long long sys_stride) {
+  extern __shared__ char smem[];
+  cplx* sT = (cplx*)smem;                               // [H2]
+  cplx* sC = sT + H2;                                   // [H] column factors of the partner ball
+  double* sCoef = (double*)(sC + H);                    // [chunk_terms_max]
+  uint32_t* sPtr = (uint32_t*)(sCoef + chunk_terms_max);   // [chunk_ents_max + 1], relative to the chunk's first term
+  uint16_t* sIdx = (uint16_t*)(sPtr + chunk_ents_max + 1);
+  const int chunk = blockIdx.x, b = blockIdx.y, s = blockIdx.z, tid = threadIdx.x;
+  const int e0 = chunk_ent[chunk], e1 = chunk_ent[chunk + 1], nent = e1 - e0;
+  const uint32_t t0 = ptr[e0], t1 = ptr[e1];
+  for (uint32_t q = t0 + tid; q < t1; q += FILL_THREADS) { sCoef[q - t0] = coef[q]; sIdx[q - t0] = tidx[q]; }
+  for (int e = tid; e <= nent; e += FILL_THREADS) sPtr[e] = ptr[e0 + e] - t0;
   const cplx* tb = tab + ((size_t)s * B + b) * 3 * n_end;
-  const cplx* tbp = tab + ((size_t)s * B + bp) * 3 * n_end;
-  if (b == bp) {
-    for (int r = 0; r < ROWS; ++r) {
-      int h = h0 + r;
-      if (h >= H) break;
-      int n = deg[h];
-      cplx dg = scaling == BIEM_FILL_REFERENCE ? cmul(tb[n_end + n], tb[2 * n_end + n]) : make_double2(1.0, 0.0);
-      for (int hp = threadIdx.x; hp < H; hp += 256) Ab[(size_t)h * lda + hp] = (hp == h) ? dg : make_double2(0.0, 0.0);
-    }
-    return;
-  }
-  const cplx* Tp = T + ((size_t)s * B * B + pair) * H2;
-  for (int l = threadIdx.x; l < H2; l += 256) sT[l] = Tp[l];
-  for (int hp = threadIdx.x; hp < H; hp += 256) {
-    int n = deg[hp];
-    sC[hp] = scaling == BIEM_FILL_REFERENCE ? tbp[2 * n_end + n] : crecip(tbp[n_end + n]);
-  }
-  __syncthreads();
-  for (int r = 0; r < ROWS; ++r) {
-    int h = h0 + r;
-    if (h >= H) break;
-    cplx rowf = tb[deg[h]];   // gj
-    const uint32_t* pr = ptr + (size_t)h * H;
-    for (int hp = threadIdx.x; hp < H; hp += 256) {
-      uint32_t p0 = pr[hp], p1 = pr[hp + 1];
-      double ar = 0.0, ai = 0.0;
-      for (uint32_t q = p0; q < p1; ++q) {
-        double c = coef[q];
-        cplx t = sT[tidx[q]];
-        ar = fma(c, t.x, ar);
-        ai = fma(c, t.y, ai);
+  cplx* Arow = A + (size_t)s * sys_stride + ((size_t)b * H) * lda;
+  for (int bp = 0; bp < B; ++bp) {
+    cplx* Ab = Arow + (size_t)bp * H;
+    if (bp == b) {
+      for (int e = tid; e < nent; e += FILL_THREADS) {
+        int h = (e0 + e) / H, hp = (e0 + e) - h * H;
+        cplx v = make_double2(0.0, 0.0);
+        if (hp == h) {
+          int n = deg[h];
+          v = scaling == BIEM_FILL_REFERENCE ? cmul(tb[n_end + n], tb[2 * n_end + n]) : make_double2(1.0, 0.0);
+        }
+        Ab[(size_t)h * lda + hp] = v;
       }
-      cplx v = cmul(cmul(make_double2(ar, ai), rowf), sC[hp]);
-      Ab[(size_t)h * lda + hp] = v;
+      continue;
+    }
+    const cplx* tbp = tab + ((size_t)s * B + bp) * 3 * n_end;
+    const cplx* Tp = T + ((size_t)s * B * B + (size_t)b * B + bp) * H2;
+    __syncthreads();                                     // previous partner's table no longer in use (also orders the chunk loads)
+    for (int l = tid; l < H2; l += FILL_THREADS) sT[l] = Tp[l];
+    for (int hp = tid; hp < H; hp += FILL_THREADS) {
+      int n = deg[hp];
+      sC[hp] = scaling == BIEM_FILL_REFERENCE ? tbp[2 * n_end + n] : crecip(tbp[n_end + n]);
+    }
+    __syncthreads();
+    for (int e = tid; e < nent; e += 2 * FILL_THREADS) {
+      const int eb = e + FILL_THREADS;
+      const bool two = eb < nent;
+      uint32_t p0 = sPtr[e], p1 = sPtr[e + 1];
+      uint32_t q0 = two ? sPtr[eb] : 0, q1 = two ? sPtr[eb + 1] : 0;
+      double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
+      while (p0 < p1 && q0 < q1) {                       // two independent chains
+        double c = sCoef[p0], d = sCoef[q0];
+        cplx t = sT[sIdx[p0]], u = sT[sIdx[q0]];
+        ar = fma(c, t.x, ar); ai = fma(c, t.y, ai);
+        br = fma(d, u.x, br); bi = fma(d, u.y, bi);
+        ++p0; ++q0;
+      }
+      for (; p0 < p1; ++p0) { double c = sCoef[p0]; cplx t = sT[sIdx[p0]]; ar = fma(c, t.x, ar); ai = fma(c, t.y, ai); }
+      for (; q0 < q1; ++q0) { double d = sCoef[q0]; cplx u = sT[sIdx[q0]]; br = fma(d, u.x, br); bi = fma(d, u.y, bi); }
+      {
+        int h = (e0 + e) / H, hp = (e0 + e) - h * H;
+        Ab[(size_t)h * lda + hp] = cmul(cmul(make_double2(ar, ai), tb[deg[h]]), sC[hp]);
+      }
+      if (two) {
+        int h = (e0 + eb) / H, hp = (e0 + eb) - h * H;
+        Ab[(size_t)h * lda + hp] = cmul(cmul(make_double2(br, bi), tb[deg[h]]), sC[hp]);
+      }
     }
   }
 }
@@ -240,12 +265,16 @@ int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const doub
                        p->d_deg2, B, d_k, d_centers, geom_batched, T);
     BIEM_LAUNCHCHK();
   }
-  constexpr int ROWS = 8;
-  size_t shm = (size_t)(p->H2 + H) * sizeof(cplx);
-  if (shm > 160 * 1024) { set_error("biem_fill: translation table does not fit LDS (H2=%d)", p->H2); return BIEM_ERR_UNSUPPORTED; }
-  if (shm > 64 * 1024) BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_fill<ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-  hipLaunchKernelGGL(k_fill<ROWS>, dim3((H + ROWS - 1) / ROWS, B * B, nb), dim3(256), shm, st, H, p->H2, p->n_end, B, p->d_deg,
-                     p->d_ptr, p->d_coef, p->d_tidx, T, (const cplx*)d_tab, scaling, (cplx*)d_A, lda, sys_stride);
+  size_t shm = (size_t)(p->H2 + H) * sizeof(cplx) + (size_t)p->chunk_terms_max * 10 + (size_t)(p->chunk_ents_max + 1) * 4 + 16;
+  if (shm > 160 * 1024 || p->chunk_terms_max == 0 && p->coef.size() > 0) {
+    set_error("biem_fill: tables do not fit LDS (H2=%d, chunk terms=%d)", p->H2, p->chunk_terms_max);
+    return BIEM_ERR_UNSUPPORTED;
+  }
+  BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+  const int nchunks = (int)p->chunk_ent.size() - 1;
+  hipLaunchKernelGGL(k_fill, dim3(nchunks, B, nb), dim3(FILL_THREADS), shm, st, H, p->H2, p->n_end, B, p->d_deg, p->d_chunk_ent,
+                     p->chunk_terms_max, p->chunk_ents_max, p->d_ptr, p->d_coef, p->d_tidx16, T, (const cplx*)d_tab, scaling,
+                     (cplx*)d_A, lda, sys_stride);
   BIEM_LAUNCHCHK();
   if (n_pad > N) {
     hipLaunchKernelGGL(k_fill_pad, dim3(64, nb), dim3(256), 0, st, N, n_pad, (cplx*)d_A, lda, sys_stride);

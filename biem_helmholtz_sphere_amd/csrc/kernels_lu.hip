@@ -28,7 +28,8 @@ static inline long long ldp_of(int n_pad) { return (long long)n_pad; }
 
 size_t lu_workspace_bytes(int nb, int n_pad, int nrhs) {
   (void)nrhs;
-  return (size_t)nb * 2 * NB * (size_t)ldp_of(n_pad) * sizeof(cplx);   // two 64-column panels (one K = 128 block)
+  // two 64-column panels (one K = 128 block) + the 64 x 64 operand I - L11^{-1} of the MFMA triangular solve
+  return (size_t)nb * (2 * NB * (size_t)ldp_of(n_pad) + (size_t)NB * NB) * sizeof(cplx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -537,7 +538,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_stream(cplx* __restrict__ A, lo
 
 // C[row_begin:row_end, col_begin:col_end] -= P[0:kd]^T (rows of the region) * M[brow:brow+kd, cols of the region]
 static void launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, long long sys_stride, const cplx* Pw, long long ldp,
-                               long long p_stride, int row_begin, int row_end, int col_begin, int col_end, int brow, int kd) {
+                               long long p_stride, int row_begin, int row_end, int col_begin, int col_end, int brow, int kd,
+                               int prof_class = PK_GEMM, double prof_work = -1.0) {
   const int rrows = row_end - row_begin, rcols = col_end - col_begin;
   if (rrows <= 0 || rcols <= 0) return;
   TileGrid tg;
@@ -546,11 +548,40 @@ static void launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, l
   tg.row_begin = row_begin; tg.row_end = row_end; tg.col_begin = col_begin; tg.col_end = col_end; tg.brow = brow;
   int want = (tg.ntiles + 7) / 8 * 8;          // one workgroup per tile, capped at 2 per CU, multiple of 8
   int grid = want < 512 ? want : 512;
-  ProfScope ps(PK_GEMM, st, 8.0 * (double)nb * rrows * (double)rcols * kd);
+  ProfScope ps(prof_class, st, prof_work >= 0.0 ? prof_work : 8.0 * (double)nb * rrows * (double)rcols * kd);
   if (kd == 64)
     hipLaunchKernelGGL(k_gemm_stream<64>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
   else
     hipLaunchKernelGGL(k_gemm_stream<128>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
+}
+
+// W = I - L11^{-1} for the unit-lower 64 x 64 diagonal block of a panel, stored [k][i] (the MFMA A-operand order), so that
+//   U12 = L11^{-1} A12 = A12 - W A12
+// runs on the streaming zgemm (C -= A*B with B = C's own rows; a tile reads all of its 64 x 128 block before it stores).
+// One 64-thread workgroup per system; thread c owns column c of the inverse (forward substitution in LDS).
+__global__ void __launch_bounds__(64) k_inv_l11(const cplx* __restrict__ Pj, long long ldp, long long p_stride, int j,
+                                                 cplx* __restrict__ Winv) {
+  extern __shared__ cplx sm[];
+  cplx* sLT = sm;               // sLT[k][r] = L[r][k]
+  cplx* sW = sm + NB * NB;      // sW[r][c]
+  const int s = blockIdx.x, c = threadIdx.x;
+  const cplx* Ps = Pj + (size_t)s * p_stride;
+  for (int k = 0; k < NB; ++k) {
+    sLT[k * NB + c] = Ps[(size_t)k * ldp + j + c];
+    sW[k * NB + c] = (k == c) ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  for (int r = 1; r < NB; ++r) {
+    cplx acc = make_double2(0.0, 0.0);
+    for (int k = 0; k < r; ++k) acc = cfma(sLT[k * NB + r], sW[k * NB + c], acc);
+    if (r > c) sW[r * NB + c] = make_double2(-acc.x, -acc.y);
+  }
+  __syncthreads();
+  cplx* Wo = Winv + (size_t)s * NB * NB;
+  for (int k = 0; k < NB; ++k) {
+    cplx v = sW[c * NB + k];                                   // inverse[i = c][k]
+    Wo[k * NB + c] = (c > k) ? make_double2(-v.x, -v.y) : make_double2(0.0, 0.0);
+  }
 }
 
 // apply the row interchanges of the second panel of a block to the stored multipliers of the first (P columns 0..NB-1)
@@ -621,6 +652,11 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
   const int n_cols = n_pad + nrhs;
   static const int gemm_variant = getenv("BIEM_GEMM_V1") ? 1 : 2;   // A/B switch for the design notes; v2 is the product
   hipLaunchKernelGGL(k_zero_int, dim3((nb + 63) / 64), dim3(64), 0, st, d_info, nb);
+  static bool inv_attr = false;
+  if (!inv_attr) {
+    BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_inv_l11, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * NB * NB * sizeof(cplx))));
+    inv_attr = true;
+  }
 
   // factor the 64-column panel at column j, multipliers into P columns [pc, pc + NB)
   auto panel = [&](int j, int pc) {
@@ -640,12 +676,23 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     hipLaunchKernelGGL(k_swap, dim3((rcols + 255) / 256, nb), dim3(256), 0, st, A, lda, sys_stride, n_pad, n_cols, j, d_ipiv, 0);
   };
   // U row block: M[j:j+NB, j+NB:] <- L11^{-1} M[j:j+NB, j+NB:]
+  cplx* Winv = Pw + (size_t)nb * p_stride;
   auto trsm = [&](int j, int pc) {
     const int rcols = n_cols - (j + NB);
     if (rcols <= 0) return;
-    ProfScope ps(PK_TRSM, st, 4.0 * (double)nb * NB * NB * rcols);
-    hipLaunchKernelGGL(k_trsm, dim3((rcols + TC - 1) / TC, nb), dim3(256), 0, st, A, lda, sys_stride, Pw + (size_t)pc * ldp, ldp,
-                       p_stride, n_cols, j);
+    const double work = 4.0 * (double)nb * NB * NB * rcols;
+    if (gemm_variant == 1) {
+      ProfScope ps(PK_TRSM, st, work);
+      hipLaunchKernelGGL(k_trsm, dim3((rcols + TC - 1) / TC, nb), dim3(256), 0, st, A, lda, sys_stride, Pw + (size_t)pc * ldp, ldp,
+                         p_stride, n_cols, j);
+      return;
+    }
+    {
+      ProfScope ps(PK_TRSM, st, 0.0);
+      hipLaunchKernelGGL(k_inv_l11, dim3(nb), dim3(64), 2 * NB * NB * sizeof(cplx), st, Pw + (size_t)pc * ldp, ldp, p_stride, j, Winv);
+    }
+    // A operand W[k][i], i = row - j: hand the kernel the base shifted by -j rows (only rows j .. j+63 are addressed)
+    launch_gemm_stream(st, nb, A, lda, sys_stride, Winv - j, NB, (long long)NB * NB, j, j + NB, j + NB, n_cols, j, NB, PK_TRSM, work);
   };
 
   if (gemm_variant == 1) {

@@ -203,6 +203,29 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
       p->ptr[(size_t)h * H + hp + 1] = (uint32_t)p->coef.size();
     }
   }
+  // ---- entry chunks of the fill kernel: term slice + row pointers + pair table + column factors must fit LDS ----
+  p->tidx16.resize(p->tidx.size());
+  for (size_t i = 0; i < p->tidx.size(); ++i) p->tidx16[i] = (uint16_t)p->tidx[i];
+  {
+    const int max_ents = 4096;
+    const long long budget = 150 * 1024 - (long long)(p->H2 + H) * 16 - (long long)(max_ents + 1) * 4 - 64;
+    long long cap_terms = budget > 0 ? budget / 10 : 0;            // 8-byte coefficient + 2-byte table index per term
+    if (cap_terms > 16384) cap_terms = 16384;
+    const long long total = (long long)H * H;
+    p->chunk_ent.clear();
+    p->chunk_ent.push_back(0);
+    p->chunk_terms_max = 0; p->chunk_ents_max = 0;
+    long long e0 = 0;
+    while (e0 < total) {
+      long long e1 = e0 + 1;
+      while (e1 < total && e1 - e0 < max_ents && (long long)(p->ptr[e1 + 1] - p->ptr[e0]) <= cap_terms) ++e1;
+      int nt = (int)(p->ptr[e1] - p->ptr[e0]);
+      if (nt > p->chunk_terms_max) p->chunk_terms_max = nt;
+      if ((int)(e1 - e0) > p->chunk_ents_max) p->chunk_ents_max = (int)(e1 - e0);
+      p->chunk_ent.push_back((int)e1);
+      e0 = e1;
+    }
+  }
   return BIEM_OK;
 }
 
@@ -228,6 +251,8 @@ int plan_upload(biem_plan* p) {
   if ((rc = up(&p->d_ptr, p->ptr))) return rc;
   if ((rc = up(&p->d_coef, p->coef))) return rc;
   if ((rc = up(&p->d_tidx, p->tidx))) return rc;
+  if ((rc = up(&p->d_tidx16, p->tidx16))) return rc;
+  if ((rc = up(&p->d_chunk_ent, p->chunk_ent))) return rc;
   p->device = dev;
   return BIEM_OK;
 }
@@ -236,6 +261,7 @@ void plan_free(biem_plan* p) {
   if (p->device >= 0) {
     (void)hipFree(p->d_labels); (void)hipFree(p->d_deg); (void)hipFree(p->d_labels2); (void)hipFree(p->d_deg2);
     (void)hipFree(p->d_W); (void)hipFree(p->d_ptr); (void)hipFree(p->d_coef); (void)hipFree(p->d_tidx);
+    (void)hipFree(p->d_tidx16); (void)hipFree(p->d_chunk_ent);
   }
   delete p;
 }

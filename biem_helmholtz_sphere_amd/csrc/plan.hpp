@@ -17,12 +17,17 @@ struct biem_plan {
   std::vector<uint32_t> ptr;                // [H*H + 1]
   std::vector<double> coef;                 // [terms]
   std::vector<int32_t> tidx;                // [terms]
+  std::vector<uint16_t> tidx16;             // same, 16-bit copy the fill kernel keeps in LDS
+  std::vector<int> chunk_ent;               // fill chunks: entries e = h*H + h' in [chunk_ent[c], chunk_ent[c+1]); sized to the LDS budget
+  int chunk_terms_max = 0;                  // largest number of terms in one chunk
+  int chunk_ents_max = 0;                   // largest number of entries in one chunk
   // device mirrors (null until uploaded)
   int device = -1;
   int* d_labels = nullptr; int* d_deg = nullptr;
   int* d_labels2 = nullptr; int* d_deg2 = nullptr;
   double* d_W = nullptr;
   uint32_t* d_ptr = nullptr; double* d_coef = nullptr; int32_t* d_tidx = nullptr;
+  uint16_t* d_tidx16 = nullptr; int* d_chunk_ent = nullptr;
 };
 
 namespace biem {
