@@ -72,113 +72,132 @@ __global__ void __launch_bounds__(256) k_panel_store(cplx* __restrict__ A, long 
 
 // ---------------------------------------------------------------------------------------------
 // panel factorisation: LU with partial pivoting of the column-major panel, blocked in strips of PW columns.
-//   strip  : unblocked right-looking elimination confined to the strip's PW columns (pivot = max |re| + |im|,
-//            LAPACK izamax's cabs1, ties -> smallest row; the row interchange is applied to all NB columns)
-//   right  : U_strip,right = L_strip^{-1} P[strip rows, right columns], then one rank-PW update of the rows below
-// The unblocked form swept the whole remaining panel once per column (NB^2/2 column passes through L2: 2.2 ms per
-// 6400 x 64 panel, profiles/r01_v1_kernel_stats_cfg3_8sys.csv); the strips cut that traffic ~4x.
-// One 1024-thread workgroup per system.
+//   k_panel_strip  (one 1024-thread workgroup per system): unblocked right-looking elimination confined to the strip's PW
+//                  columns (pivot = max |re| + |im|, LAPACK izamax's cabs1, ties -> smallest row; the interchange is
+//                  applied to all NB panel columns; the pass that writes column c+1 also searches it), then
+//                  U_strip,right = L_strip^{-1} P[strip rows, right columns]
+//   k_panel_update (all CUs): the rank-PW update of the rows below the strip on the right columns
+// History (profiles/): unblocked sweep 2.15 ms per 6400 x 64 panel (NB^2/2 column passes through L2); strips inside one
+// workgroup 0.89 ms, then f64-VALU bound: the rank-8 updates are 92 MFLOP on ONE CU, and 32 systems keep only 32 of 256
+// CUs busy - hence the update runs as its own launch over the whole chip.
 // ---------------------------------------------------------------------------------------------
 constexpr int PW = 8;
 
-__global__ void __launch_bounds__(1024) k_panel_factor(cplx* __restrict__ Pw, long long ldp, long long p_stride, int n_pad, int j,
-                                                        int* __restrict__ ipiv, int* __restrict__ info) {
-  __shared__ double sval[16];
-  __shared__ int sidx[16];
+__global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, long long ldp, long long p_stride, int n_pad, int j, int c0,
+                                                       int* __restrict__ ipiv, int* __restrict__ info) {
+  __shared__ double sval[2][16];   // per-wave pivot candidates, double-buffered over columns
+  __shared__ int sidx[2][16];
   __shared__ cplx sU[PW];          // current pivot row restricted to the strip
   __shared__ cplx sL[PW][PW];      // unit-lower strip triangle
-  __shared__ cplx sUr[PW][NB];     // U rows of the strip for the right columns
-  __shared__ int sPiv;
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   cplx* Ps = Pw + (size_t)s * p_stride;
-  for (int c0 = 0; c0 < NB; c0 += PW) {
-    for (int c = c0; c < c0 + PW; ++c) {
-      cplx* col = Ps + (size_t)c * ldp;
-      const int r0 = j + c;
-      double best = -1.0;
-      int bi = 0x7fffffff;
-      for (int i = r0 + tid; i < n_pad; i += 1024) {
-        cplx v = col[i];
-        double a = fabs(v.x) + fabs(v.y);
-        if (a > best) { best = a; bi = i; }
-      }
-      for (int o = 32; o > 0; o >>= 1) {
-        double ob = __shfl_down(best, o, 64);
-        int oi = __shfl_down(bi, o, 64);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-      }
-      if (lane == 0) { sval[wave] = best; sidx[wave] = bi; }
-      __syncthreads();
-      if (tid == 0) {
-        double b = sval[0]; int ix = sidx[0];
-        for (int w = 1; w < 16; ++w) if (sval[w] > b || (sval[w] == b && sidx[w] < ix)) { b = sval[w]; ix = sidx[w]; }
-        if (ix == 0x7fffffff) ix = r0;   // all-NaN column: keep the diagonal
-        sPiv = ix;
-        ipiv[(size_t)s * n_pad + r0] = ix;
-      }
-      __syncthreads();
-      const int p = sPiv;
-      if (tid < NB) {
-        cplx a = Ps[(size_t)tid * ldp + r0];
-        if (p != r0) {
-          cplx b = Ps[(size_t)tid * ldp + p];
-          Ps[(size_t)tid * ldp + p] = a;
-          Ps[(size_t)tid * ldp + r0] = b;
-          a = b;
-        }
-        if (tid >= c0 && tid < c0 + PW) sU[tid - c0] = a;   // row r0 after the interchange, strip columns
-      }
-      __syncthreads();
-      const cplx piv = sU[c - c0];
-      if (piv.x == 0.0 && piv.y == 0.0) {
-        if (tid == 0 && info[s] == 0) info[s] = r0 + 1;
-        continue;   // uniform: exactly singular column, nothing to eliminate
-      }
-      const cplx rinv = crecip(piv);
-      for (int i = r0 + 1 + tid; i < n_pad; i += 1024) {
-        cplx l = cmul(col[i], rinv);
-        col[i] = l;
-        for (int cc = c + 1; cc < c0 + PW; ++cc) {
-          cplx* q = Ps + (size_t)cc * ldp + i;
-          *q = cfnma(l, sU[cc - c0], *q);
-        }
-      }
-      __syncthreads();
+
+  auto publish = [&](double best, int bi, int buf) {
+    for (int o = 32; o > 0; o >>= 1) {
+      double ob = __shfl_down(best, o, 64);
+      int oi = __shfl_down(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
-    const int nright = NB - (c0 + PW);
-    if (nright <= 0) break;
-    const int rs = j + c0;               // first row of the strip
-    if (tid < PW * PW) {
-      int q = tid / PW, q2 = tid % PW;   // L[q][q2], q2 < q
-      sL[q][q2] = (q2 < q) ? Ps[(size_t)(c0 + q2) * ldp + rs + q] : make_double2(0.0, 0.0);
+    if (lane == 0) { sval[buf][wave] = best; sidx[buf][wave] = bi; }
+  };
+  auto decide = [&](int buf, int r0) -> int {   // every thread reduces the 16 candidates redundantly (no extra barrier)
+    double b = sval[buf][0]; int ix = sidx[buf][0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) { double v = sval[buf][w]; int i2 = sidx[buf][w]; if (v > b || (v == b && i2 < ix)) { b = v; ix = i2; } }
+    return ix == 0x7fffffff ? r0 : ix;          // all-NaN column: keep the diagonal
+  };
+
+  {  // search the strip's first column
+    const cplx* col = Ps + (size_t)c0 * ldp;
+    double best = -1.0; int bi = 0x7fffffff;
+    for (int i = j + c0 + tid; i < n_pad; i += 1024) {
+      cplx v = col[i];
+      double a = fabs(v.x) + fabs(v.y);
+      if (a > best) { best = a; bi = i; }
+    }
+    publish(best, bi, 0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int c = c0; c < c0 + PW; ++c) {
+    cplx* col = Ps + (size_t)c * ldp;
+    const int r0 = j + c;
+    const int p = decide(buf, r0);
+    if (tid == 0) ipiv[(size_t)s * n_pad + r0] = p;
+    if (tid < NB) {
+      cplx a = Ps[(size_t)tid * ldp + r0];
+      if (p != r0) {
+        cplx b = Ps[(size_t)tid * ldp + p];
+        Ps[(size_t)tid * ldp + p] = a;
+        Ps[(size_t)tid * ldp + r0] = b;
+        a = b;
+      }
+      if (tid >= c0 && tid < c0 + PW) sU[tid - c0] = a;   // row r0 after the interchange, strip columns
     }
     __syncthreads();
-    if (tid < nright) {
-      cplx* colr = Ps + (size_t)(c0 + PW + tid) * ldp + rs;
-      cplx x[PW];
-#pragma unroll
-      for (int q = 0; q < PW; ++q) x[q] = colr[q];
-#pragma unroll
-      for (int q = 1; q < PW; ++q)
-#pragma unroll
-        for (int q2 = 0; q2 < q; ++q2) x[q] = cfnma(sL[q][q2], x[q2], x[q]);
-#pragma unroll
-      for (int q = 0; q < PW; ++q) { colr[q] = x[q]; sUr[q][tid] = x[q]; }
-    }
-    __syncthreads();
-    for (int i = rs + PW + tid; i < n_pad; i += 1024) {
-      cplx l[PW];
-#pragma unroll
-      for (int q = 0; q < PW; ++q) l[q] = Ps[(size_t)(c0 + q) * ldp + i];
-      for (int t = 0; t < nright; ++t) {
-        cplx* q_ = Ps + (size_t)(c0 + PW + t) * ldp + i;
-        cplx v = *q_;
-#pragma unroll
-        for (int q = 0; q < PW; ++q) v = cfnma(l[q], sUr[q][t], v);
-        *q_ = v;
+    const cplx piv = sU[c - c0];
+    const bool singular = piv.x == 0.0 && piv.y == 0.0;
+    if (singular && tid == 0 && info[s] == 0) info[s] = r0 + 1;
+    const cplx rinv = singular ? make_double2(0.0, 0.0) : crecip(piv);
+    const bool inner = c + 1 < c0 + PW;
+    double best = -1.0; int bi = 0x7fffffff;
+    for (int i = r0 + 1 + tid; i < n_pad; i += 1024) {
+      cplx l = col[i];
+      if (!singular) { l = cmul(l, rinv); col[i] = l; }
+      for (int cc = c + 1; cc < c0 + PW; ++cc) {
+        cplx* q = Ps + (size_t)cc * ldp + i;
+        cplx v = singular ? *q : cfnma(l, sU[cc - c0], *q);
+        *q = v;
+        if (cc == c + 1) { double a = fabs(v.x) + fabs(v.y); if (a > best) { best = a; bi = i; } }
       }
     }
+    if (inner) { publish(best, bi, buf ^ 1); buf ^= 1; }
     __syncthreads();
+  }
+  const int nright = NB - (c0 + PW);
+  if (nright <= 0) return;
+  const int rs = j + c0;               // first row of the strip
+  if (tid < PW * PW) {
+    int q = tid / PW, q2 = tid % PW;   // L[q][q2], q2 < q
+    sL[q][q2] = (q2 < q) ? Ps[(size_t)(c0 + q2) * ldp + rs + q] : make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  if (tid < nright) {
+    cplx* colr = Ps + (size_t)(c0 + PW + tid) * ldp + rs;
+    cplx x[PW];
+#pragma unroll
+    for (int q = 0; q < PW; ++q) x[q] = colr[q];
+#pragma unroll
+    for (int q = 1; q < PW; ++q)
+#pragma unroll
+      for (int q2 = 0; q2 < q; ++q2) x[q] = cfnma(sL[q][q2], x[q2], x[q]);
+#pragma unroll
+    for (int q = 0; q < PW; ++q) colr[q] = x[q];
+  }
+}
+
+// rows below the strip, right columns:  P[cc][i] -= sum_q L[i][q] U[q][cc];  one thread per row, all CUs
+__global__ void __launch_bounds__(256) k_panel_update(cplx* __restrict__ Pw, long long ldp, long long p_stride, int n_pad, int j, int c0) {
+  __shared__ cplx sUr[PW][NB];
+  const int s = blockIdx.y, tid = threadIdx.x;
+  cplx* Ps = Pw + (size_t)s * p_stride;
+  const int rs = j + c0, nright = NB - (c0 + PW);
+  for (int e = tid; e < nright * PW; e += 256) {
+    int t = e / PW, q = e % PW;
+    sUr[q][t] = Ps[(size_t)(c0 + PW + t) * ldp + rs + q];
+  }
+  __syncthreads();
+  const int i = rs + PW + blockIdx.x * 256 + tid;
+  if (i >= n_pad) return;
+  cplx l[PW];
+#pragma unroll
+  for (int q = 0; q < PW; ++q) l[q] = Ps[(size_t)(c0 + q) * ldp + i];
+  for (int t = 0; t < nright; ++t) {
+    cplx* q_ = Ps + (size_t)(c0 + PW + t) * ldp + i;
+    cplx v = *q_;
+#pragma unroll
+    for (int q = 0; q < PW; ++q) v = cfnma(l[q], sUr[q][t], v);
+    *q_ = v;
   }
 }
 
@@ -664,7 +683,12 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     const int rows = n_pad - j;
     ProfScope ps(PK_PANEL, st, 4.0 * (double)nb * rows * NB * NB);
     hipLaunchKernelGGL(k_panel_load, dim3((rows + TR - 1) / TR, nb), dim3(256), 0, st, A, lda, sys_stride, Pj, ldp, p_stride, n_pad, j);
-    hipLaunchKernelGGL(k_panel_factor, dim3(nb), dim3(1024), 0, st, Pj, ldp, p_stride, n_pad, j, d_ipiv, d_info);
+    for (int c0 = 0; c0 < NB; c0 += PW) {
+      hipLaunchKernelGGL(k_panel_strip, dim3(nb), dim3(1024), 0, st, Pj, ldp, p_stride, n_pad, j, c0, d_ipiv, d_info);
+      const int below = n_pad - (j + c0 + PW);
+      if (c0 + PW < NB && below > 0)
+        hipLaunchKernelGGL(k_panel_update, dim3((below + 255) / 256, nb), dim3(256), 0, st, Pj, ldp, p_stride, n_pad, j, c0);
+    }
     hipLaunchKernelGGL(k_panel_store, dim3((rows + TR - 1) / TR, nb), dim3(256), 0, st, A, lda, sys_stride, Pj, ldp, p_stride, n_pad, j);
     if (pc > 0) hipLaunchKernelGGL(k_swap_p, dim3(nb), dim3(64), 0, st, Pw, ldp, p_stride, n_pad, j, d_ipiv);
   };
