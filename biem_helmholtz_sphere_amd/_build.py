@@ -31,6 +31,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB
     cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB]
+    cmd += os.environ.get("BIEM_HIPCC_FLAGS", "").split()      # experiments only
     cmd += [os.path.join(CSRC, f) for f in SOURCES]
     if verbose:
         print(" ".join(cmd))

@@ -14,6 +14,7 @@
 // then a blocked back substitution with U.  All kernels are batched over systems (blockIdx.z / .y).
 #include "common.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 namespace biem {
 
@@ -555,23 +556,473 @@ __global__ void __launch_bounds__(256, 2) k_gemm_stream(cplx* __restrict__ A, lo
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// trailing update, 3M form (default): the same streaming schedule with 3 real products per complex product
+//   T1 = Ar Br,  T2 = Ai Bi,  T3 = (Ar + Ai)(Br + Bi);   Re(AB) = T1 - T2,  Im(AB) = T3 - T1 - T2     (as in BLAS zgemm3m)
+// i.e. 25 % fewer MFMAs for the same 8 flop per complex multiply-add of algorithmic work.  Three accumulator sets per
+// sub-tile: N1 = Cr - T1,  P2 = T2,  N3 = (Cr + Ci) - T3;  result Cr' = N1 + P2,  Ci' = N3 - N1 + P2.
+// The rounding is norm-wise (|Ar|+|Ai|)(|Br|+|Bi|) eps instead of component-wise - far inside the 1e-10 budget of the path.
+// Workgroup = 256 threads (2 x 2 waves, wave tile 32 x 32), tile 64 x 64, 32 KiB LDS, <= 168 VGPRs: three per CU.
+// ---------------------------------------------------------------------------------------------
+constexpr int BM3 = 64, BN3 = 64;
+
+template <int KD>
+__global__ void __launch_bounds__(256, 3) k_gemm3m_stream(cplx* __restrict__ A, long long lda, long long sys_stride,
+                                                           const cplx* __restrict__ Pw, long long ldp, long long p_stride,
+                                                           TileGrid tg) {
+  const int n_pad = tg.row_end, n_cols = tg.col_end;
+  constexpr int NCH = KD / KC;               // 8 or 16 K-chunks per tile
+  constexpr int UPC = 16 / NCH;              // C units (one complex per lane) fetched per chunk: 2 or 1
+  __shared__ cplx sA[2][KC][BM3];
+  __shared__ cplx sB[2][KC][BN3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l3 = lane & 3, l15 = lane & 15, l4 = lane >> 4;
+  // tile sequence: label x = w % 8 owns the 64-tile blocks x, x + 8, ..; its workgroups r = w / 8 take positions
+  // r, r + nblk, .. of the label's concatenated block sequence
+  const int w = blockIdx.x, nblk = gridDim.x >> 3, xl = w & 7;
+  int q = (w >> 3) - nblk;
+  auto next_tile = [&]() -> int {
+    for (;;) {
+      q += nblk;
+      int base = 64 * ((q >> 6) * 8 + xl);
+      if (base >= tg.ntiles) return -1;
+      int t = base + (q & 63);
+      if (t < tg.ntiles) return t;
+    }
+  };
+  int t = next_tile();
+  if (t < 0) return;
+
+  const cplx zero = make_double2(0.0, 0.0);
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  int cs, cty, ctx;
+  tile_decode(tg, t, cs, cty, ctx);
+  // LDS-DMA staging: wave `wave` brings k-rows wave and wave + 4 of both operands (one contiguous 1 KiB row each)
+  auto stage = [&](int s_, int ty_, int tx_, int kc, int buf) {
+    const cplx* Ps = Pw + (size_t)s_ * p_stride;
+    const cplx* As = A + (size_t)s_ * sys_stride;
+    const int r0 = tg.row_begin + ty_ * BM3, c0 = tg.col_begin + tx_ * BN3;
+    if (r0 + lane < n_pad) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ps + (size_t)(kc + wave + 4 * r) * ldp + r0 + lane),
+                                         (lds_ptr_t)(&sA[buf][wave + 4 * r][0]), 16, 0, 0);
+    }
+    if (c0 + lane < n_cols) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(As + (size_t)(tg.brow + kc + wave + 4 * r) * lda + c0 + lane),
+                                         (lds_ptr_t)(&sB[buf][wave + 4 * r][0]), 16, 0, 0);
+    }
+  };
+
+  double N1[2][2][4], P2[2][2][4], N3[2][2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { N1[a][b][g] = 0.0; P2[a][b][g] = 0.0; N3[a][b][g] = 0.0; }
+
+  stage(cs, cty, ctx, 0, 0);
+  __syncthreads();
+
+  for (;;) {
+    cplx* Cs = A + (size_t)cs * sys_stride;
+    const int row0 = tg.row_begin + cty * BM3, col0 = tg.col_begin + ctx * BN3;
+    int tn_ = -1, ns = 0, nty = 0, ntx = 0;
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+      const int buf = c & 1;
+      if (c + 1 < NCH) {
+        stage(cs, cty, ctx, (c + 1) * KC, buf ^ 1);
+      } else {
+        tn_ = next_tile();
+        if (tn_ >= 0) { tile_decode(tg, tn_, ns, nty, ntx); stage(ns, nty, ntx, 0, buf ^ 1); }
+      }
+      // C units u = c*UPC + i  ->  (tm, tn, g) = (u >> 3, (u >> 2) & 1, u & 3): issued now, consumed after the MFMAs
+      cplx cl[UPC];
+#pragma unroll
+      for (int i = 0; i < UPC; ++i) {
+        const int u = c * UPC + i;
+        const int row = row0 + wm * 32 + (u >> 3) * 16 + 4 * (u & 3) + l4;
+        const int col = col0 + wn * 32 + ((u >> 2) & 1) * 16 + l15;
+        cl[i] = (col < n_cols && row < n_pad) ? Cs[(size_t)row * lda + col] : zero;
+      }
+#pragma unroll
+      for (int k4 = 0; k4 < KC / 4; ++k4) {
+        const int kk = k4 * 4 + l4;
+        cplx b[2];
+        double bs[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) { b[n] = sB[buf][kk][wn * 32 + n * 16 + l15]; bs[n] = b[n].x + b[n].y; }
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+          cplx a[4];
+          double as[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) { a[g] = sA[buf][kk][wm * 32 + tm * 16 + 4 * g + l3]; as[g] = a[g].x + a[g].y; }
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) N1[tm][n][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[g].x, b[n].x, N1[tm][n][g], 0, 0, 1);
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) P2[tm][n][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[g].y, b[n].y, P2[tm][n][g], 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) N3[tm][n][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(as[g], bs[n], N3[tm][n][g], 0, 0, 1);
+        }
+      }
+#define BIEM_CADD3(U, V) { N1[(U) >> 3][((U) >> 2) & 1][(U) & 3] += (V).x; N3[(U) >> 3][((U) >> 2) & 1][(U) & 3] += (V).x + (V).y; }
+#pragma unroll
+      for (int i = 0; i < UPC; ++i) {
+        switch (c * UPC + i) {   // wave-uniform; accumulator indices must be compile-time constants
+          case 0: BIEM_CADD3(0, cl[i]) break;   case 1: BIEM_CADD3(1, cl[i]) break;
+          case 2: BIEM_CADD3(2, cl[i]) break;   case 3: BIEM_CADD3(3, cl[i]) break;
+          case 4: BIEM_CADD3(4, cl[i]) break;   case 5: BIEM_CADD3(5, cl[i]) break;
+          case 6: BIEM_CADD3(6, cl[i]) break;   case 7: BIEM_CADD3(7, cl[i]) break;
+          case 8: BIEM_CADD3(8, cl[i]) break;   case 9: BIEM_CADD3(9, cl[i]) break;
+          case 10: BIEM_CADD3(10, cl[i]) break; case 11: BIEM_CADD3(11, cl[i]) break;
+          case 12: BIEM_CADD3(12, cl[i]) break; case 13: BIEM_CADD3(13, cl[i]) break;
+          case 14: BIEM_CADD3(14, cl[i]) break; default: BIEM_CADD3(15, cl[i]) break;
+        }
+      }
+#undef BIEM_CADD3
+      __syncthreads();
+    }
+    // Cr' = N1 + P2, Ci' = N3 - N1 + P2; plain stores stay in flight while the next tile starts
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int col = col0 + wn * 32 + n * 16 + l15;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = row0 + wm * 32 + tm * 16 + 4 * g + l4;
+          if (col < n_cols && row < n_pad)
+            Cs[(size_t)row * lda + col] = make_double2(N1[tm][n][g] + P2[tm][n][g], N3[tm][n][g] - N1[tm][n][g] + P2[tm][n][g]);
+          N1[tm][n][g] = 0.0; P2[tm][n][g] = 0.0; N3[tm][n][g] = 0.0;
+        }
+      }
+    }
+    if (tn_ < 0) break;
+    cs = ns; cty = nty; ctx = ntx;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// trailing update, 3M form with a 3-stage LDS-DMA ring (product kernel).
+// Evidence for the structure: the 2-stage kernels above run the 3M and the 4M arithmetic in the SAME time
+// (444.7 vs 447.7 ms per 32-system step) - the update is bound by the latency of loads issued one chunk ahead, not by the
+// MFMA pipe: hipcc drains vmcnt(0) at every __syncthreads() while an LDS-DMA is in flight and before any use of a
+// VGPR-destination load.  Here every byte (A chunk, B chunk and the C slice of the chunk) arrives by LDS-DMA, each wave
+// issues exactly NDMA instructions per chunk (addresses are clamped instead of masked, so the count is uniform), the
+// barrier is a raw s_barrier and the waits are hand-counted: s_waitcnt vmcnt(NDMA) retires the group of the chunk about
+// to be multiplied and leaves the next chunk's group in flight.  A full tile's 16 result stores also sit in the VM
+// queue; the first two chunks after them wait vmcnt(NDMA + 16).
+// Stage = A[8][64] + B[8][64] + C slice (UPC x 256 lanes) = 20 (K=128) or 24 KiB (K=64); 3 stages; 2 workgroups per CU.
+// ---------------------------------------------------------------------------------------------
+template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// LDS fragment read outside the compiler's memory model: hipcc orders every ds_read it can see behind ALL pending LDS-DMA
+// (s_waitcnt vmcnt(0)), which would drain the ring's prefetches; the consumer issues lds_wait() + sched_barrier itself.
+__device__ inline cplx lds_read16(const cplx* p) {
+  cplx v;
+  unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) cplx*)p;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+// acc += a*b / acc -= a*b on the 4-block f64 MFMA (the f64 NEG bit, blgp bit 0, negates A).
+// (An inline-asm form with the accumulator tied "+v" was tried to stop hipcc from rotating accumulators through the
+// register file; it produced wrong results on gfx950 even with hazard padding, and the rolled chunk loop made it
+// unnecessary - the builtin is the only form used.)
+__device__ inline void mfma_acc(double& acc, double a, double b) { acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc, 0, 0, 0); }
+__device__ inline void mfma_acc_neg(double& acc, double a, double b) { acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc, 0, 0, 1); }
+// keeps hipcc from moving VALU work into the MFMA block (and the MFMAs out of it)
+__device__ inline void mfma_fence() { __builtin_amdgcn_sched_barrier(0); }
+__device__ inline void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);   // keep MFMAs behind the wait (hipcc moves register-only instructions across asm)
+}
+
+// What the ISA of earlier attempts taught (all measured):
+//  * hipcc puts s_waitcnt vmcnt(0) in front of every ds_read it can see while an LDS-DMA is pending (even with one
+//    __shared__ array per stage) -> fragment reads are inline asm with an explicit lgkmcnt wait;
+//  * unrolling the chunk loop (3 stage copies) made hipcc rotate the 48 accumulators through the register file and copy
+//    them back with ~100-200 v_mov_b64 per chunk (they share the SIMD's vector issue port with the MFMAs) -> one rolled
+//    chunk loop with a run-time stage offset;
+//  * per-lane 64-bit address arithmetic for 5 DMAs per chunk cost ~250 VALU instructions -> wave-uniform scalar bases plus
+//    per-lane 32-bit offsets that are constant for the whole kernel.
+template <int KD>
+__global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, long long lda, long long sys_stride,
+                                                         const cplx* __restrict__ Pw, long long ldp, long long p_stride,
+                                                         TileGrid tg) {
+  const int n_pad = tg.row_end, n_cols = tg.col_end;
+  constexpr int NCH = KD / KC;               // 8 or 16 K-chunks per tile
+  constexpr int UPC = 16 / NCH;              // C units (one complex per lane) per chunk: 2 or 1
+  constexpr int NDMA = 4 + UPC;              // LDS-DMA instructions per wave per chunk
+  constexpr int STG = 2 * KC * 64 + UPC * 256;   // complex elements per stage
+  __shared__ cplx ring[3 * STG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l3 = lane & 3, l15 = lane & 15, l4 = lane >> 4;
+  const int w = blockIdx.x, nblk = gridDim.x >> 3, xl = w & 7;
+  int q = (w >> 3) - nblk;
+  auto next_tile = [&]() -> int {
+    for (;;) {
+      q += nblk;
+      int base = 64 * ((q >> 6) * 8 + xl);
+      if (base >= tg.ntiles) return -1;
+      int t = base + (q & 63);
+      if (t < tg.ntiles) return t;
+    }
+  };
+  int t = next_tile();
+  if (t < 0) return;
+
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  int cs, cty, ctx, ns = 0, nty = 0, ntx = 0;
+  tile_decode(tg, t, cs, cty, ctx);
+
+  const unsigned offA0 = (unsigned)(((size_t)(wave) * ldp + lane) * sizeof(cplx));
+  const unsigned offA1 = (unsigned)(((size_t)(wave + 4) * ldp + lane) * sizeof(cplx));
+  const unsigned offB0 = (unsigned)(((size_t)(wave) * lda + lane) * sizeof(cplx));
+  const unsigned offB1 = (unsigned)(((size_t)(wave + 4) * lda + lane) * sizeof(cplx));
+  const unsigned offC = (unsigned)(((size_t)(wm * 32 + l4) * lda + wn * 32 + l15) * sizeof(cplx));
+  // DMA group of chunk `ch` of tile (s_, ty_, tx_) into stage st: exactly NDMA instructions, all lanes active
+  auto issue = [&](int st, int s_, int ty_, int tx_, int ch) {
+    cplx* S = ring + st * STG;
+    const int r0 = tg.row_begin + ty_ * BM3, c0 = tg.col_begin + tx_ * BN3;
+    const bool interior = r0 + BM3 <= n_pad && c0 + BN3 <= n_cols;      // wave-uniform
+    if (interior) {
+      const char* bA = (const char*)(Pw + ((size_t)s_ * p_stride + (size_t)(ch * KC) * ldp + r0));
+      const char* bB = (const char*)(A + ((size_t)s_ * sys_stride + (size_t)(tg.brow + ch * KC) * lda + c0));
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(bA + offA0), (lds_ptr_t)(S + wave * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(bA + offA1), (lds_ptr_t)(S + (wave + 4) * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(bB + offB0), (lds_ptr_t)(S + KC * 64 + wave * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(bB + offB1), (lds_ptr_t)(S + KC * 64 + (wave + 4) * 64), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < UPC; ++i) {
+        const int u = ch * UPC + i;
+        const char* bC = (const char*)(A + ((size_t)s_ * sys_stride + (size_t)(r0 + (u >> 3) * 16 + 4 * (u & 3)) * lda + c0 + ((u >> 2) & 1) * 16));
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(bC + offC), (lds_ptr_t)(S + 2 * KC * 64 + i * 256 + wave * 64), 16, 0, 0);
+      }
+      return;
+    }
+    // edge tile: clamp instead of masking (the instruction count must stay uniform)
+    const cplx* Ps = Pw + (size_t)s_ * p_stride;
+    const cplx* As = A + (size_t)s_ * sys_stride;
+    const int ar = min(r0 + lane, n_pad - 1), bc = min(c0 + lane, n_cols - 1);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ps + (size_t)(ch * KC + wave + 4 * r) * ldp + ar),
+                                       (lds_ptr_t)(S + (wave + 4 * r) * 64), 16, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(As + (size_t)(tg.brow + ch * KC + wave + 4 * r) * lda + bc),
+                                       (lds_ptr_t)(S + KC * 64 + (wave + 4 * r) * 64), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < UPC; ++i) {
+      const int u = ch * UPC + i;
+      const int row = min(r0 + wm * 32 + (u >> 3) * 16 + 4 * (u & 3) + l4, n_pad - 1);
+      const int col = min(c0 + wn * 32 + ((u >> 2) & 1) * 16 + l15, n_cols - 1);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(As + (size_t)row * lda + col),
+                                       (lds_ptr_t)(S + 2 * KC * 64 + i * 256 + wave * 64), 16, 0, 0);
+    }
+  };
+
+  double N1[2][2][4], P2[2][2][4], N3[2][2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { N1[a][b][g] = 0.0; P2[a][b][g] = 0.0; N3[a][b][g] = 0.0; }
+
+  issue(0, cs, cty, ctx, 0);
+  issue(1, cs, cty, ctx, 1);
+  int st = 0;                 // stage of the chunk about to be multiplied
+  int stores_pending = 0;     // 0: none, 1: 16 stores of a full tile were issued after the groups in flight, 2: unknown count
+  // per-lane LDS offsets of the fragments inside a stage (elements)
+  const int fbo = KC * 64 + l4 * 64 + wn * 32 + l15;      // + k4*256 + n*16
+  const int fao = l4 * 64 + wm * 32 + l3;                 // + k4*256 + tm*16 + 4g
+  for (;;) {
+    int tn_ = -2;
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+      // retire this chunk's DMA group (mine), then meet the other waves: their groups have landed too and nobody still
+      // reads the stage the next group is about to overwrite
+      const bool last_group = (tn_ == -1) && (c == NCH - 1);
+      if (last_group || (stores_pending == 2 && c == 0)) wait_vmcnt<0>();
+      else if (stores_pending == 1 && c < 2) wait_vmcnt<NDMA + 16>();
+      else wait_vmcnt<NDMA>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const int st2 = st >= 1 ? st - 1 : 2;            // (st + 2) % 3
+      if (c + 2 < NCH) {
+        issue(st2, cs, cty, ctx, c + 2);
+      } else {
+        if (c == NCH - 2) {
+          tn_ = next_tile();
+          if (tn_ >= 0) tile_decode(tg, tn_, ns, nty, ntx);
+        }
+        if (tn_ >= 0) issue(st2, ns, nty, ntx, c + 2 - NCH);
+      }
+      const cplx* S = ring + st * STG;
+      // fragments of both k4-steps and the C units of this chunk: 20 + UPC ds_read_b128 and their lgkmcnt wait in ONE asm
+      // statement - hipcc may copy an asm output right after the statement, i.e. before a separate wait (that was the
+      // cause of percent-level errors in an earlier build); byte offsets: k4*4096 + tm*256 + g*64 (A), k4*4096 + n*256 (B)
+      cplx fb[2][2], fa[2][2][4], cv[UPC];
+      {
+        const unsigned aA = (unsigned)(size_t)(const __attribute__((address_space(3))) cplx*)(S + fao);
+        const unsigned aB = (unsigned)(size_t)(const __attribute__((address_space(3))) cplx*)(S + fbo);
+        const unsigned aC = (unsigned)(size_t)(const __attribute__((address_space(3))) cplx*)(S + 2 * KC * 64 + tid);
+        if constexpr (UPC == 1) {
+          asm volatile(
+              "ds_read_b128 %16, %22\n\tds_read_b128 %17, %22 offset:256\n\tds_read_b128 %18, %22 offset:4096\n\tds_read_b128 %19, %22 offset:4352\n\t"
+              "ds_read_b128 %0, %21\n\tds_read_b128 %1, %21 offset:64\n\tds_read_b128 %2, %21 offset:128\n\tds_read_b128 %3, %21 offset:192\n\t"
+              "ds_read_b128 %4, %21 offset:256\n\tds_read_b128 %5, %21 offset:320\n\tds_read_b128 %6, %21 offset:384\n\tds_read_b128 %7, %21 offset:448\n\t"
+              "ds_read_b128 %8, %21 offset:4096\n\tds_read_b128 %9, %21 offset:4160\n\tds_read_b128 %10, %21 offset:4224\n\tds_read_b128 %11, %21 offset:4288\n\t"
+              "ds_read_b128 %12, %21 offset:4352\n\tds_read_b128 %13, %21 offset:4416\n\tds_read_b128 %14, %21 offset:4480\n\tds_read_b128 %15, %21 offset:4544\n\t"
+              "ds_read_b128 %20, %23\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              : "=&v"(fa[0][0][0]), "=&v"(fa[0][0][1]), "=&v"(fa[0][0][2]), "=&v"(fa[0][0][3]), "=&v"(fa[0][1][0]), "=&v"(fa[0][1][1]),
+                "=&v"(fa[0][1][2]), "=&v"(fa[0][1][3]), "=&v"(fa[1][0][0]), "=&v"(fa[1][0][1]), "=&v"(fa[1][0][2]), "=&v"(fa[1][0][3]),
+                "=&v"(fa[1][1][0]), "=&v"(fa[1][1][1]), "=&v"(fa[1][1][2]), "=&v"(fa[1][1][3]), "=&v"(fb[0][0]), "=&v"(fb[0][1]),
+                "=&v"(fb[1][0]), "=&v"(fb[1][1]), "=&v"(cv[0])
+              : "v"(aA), "v"(aB), "v"(aC)
+              : "memory");
+        } else {
+          asm volatile(
+              "ds_read_b128 %16, %23\n\tds_read_b128 %17, %23 offset:256\n\tds_read_b128 %18, %23 offset:4096\n\tds_read_b128 %19, %23 offset:4352\n\t"
+              "ds_read_b128 %0, %22\n\tds_read_b128 %1, %22 offset:64\n\tds_read_b128 %2, %22 offset:128\n\tds_read_b128 %3, %22 offset:192\n\t"
+              "ds_read_b128 %4, %22 offset:256\n\tds_read_b128 %5, %22 offset:320\n\tds_read_b128 %6, %22 offset:384\n\tds_read_b128 %7, %22 offset:448\n\t"
+              "ds_read_b128 %8, %22 offset:4096\n\tds_read_b128 %9, %22 offset:4160\n\tds_read_b128 %10, %22 offset:4224\n\tds_read_b128 %11, %22 offset:4288\n\t"
+              "ds_read_b128 %12, %22 offset:4352\n\tds_read_b128 %13, %22 offset:4416\n\tds_read_b128 %14, %22 offset:4480\n\tds_read_b128 %15, %22 offset:4544\n\t"
+              "ds_read_b128 %20, %24\n\tds_read_b128 %21, %24 offset:4096\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              : "=&v"(fa[0][0][0]), "=&v"(fa[0][0][1]), "=&v"(fa[0][0][2]), "=&v"(fa[0][0][3]), "=&v"(fa[0][1][0]), "=&v"(fa[0][1][1]),
+                "=&v"(fa[0][1][2]), "=&v"(fa[0][1][3]), "=&v"(fa[1][0][0]), "=&v"(fa[1][0][1]), "=&v"(fa[1][0][2]), "=&v"(fa[1][0][3]),
+                "=&v"(fa[1][1][0]), "=&v"(fa[1][1][1]), "=&v"(fa[1][1][2]), "=&v"(fa[1][1][3]), "=&v"(fb[0][0]), "=&v"(fb[0][1]),
+                "=&v"(fb[1][0]), "=&v"(fb[1][1]), "=&v"(cv[0]), "=&v"(cv[UPC - 1])
+              : "v"(aA), "v"(aB), "v"(aC)
+              : "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // operand sums of the 3M form for both k4-steps, then one uninterrupted block of 96 MFMAs
+      double fbs[2][2], fas[2][2][4];
+#pragma unroll
+      for (int k4 = 0; k4 < 2; ++k4) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) fbs[k4][n] = fb[k4][n].x + fb[k4][n].y;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) fas[k4][tm][g] = fa[k4][tm][g].x + fa[k4][tm][g].y;
+      }
+      mfma_fence();
+#pragma unroll
+      for (int k4 = 0; k4 < 2; ++k4) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mfma_acc_neg(N1[tm][n][g], fa[k4][tm][g].x, fb[k4][n].x);
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mfma_acc(P2[tm][n][g], fa[k4][tm][g].y, fb[k4][n].y);
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mfma_acc_neg(N3[tm][n][g], fas[k4][tm][g], fbs[k4][n]);
+        }
+      }
+      mfma_fence();
+      // this chunk's C units (u = c*UPC + i -> sub-tile (u>>3, (u>>2)&1), register u&3) join their accumulators
+#define BIEM_CADD3(U, V) { N1[(U) >> 3][((U) >> 2) & 1][(U) & 3] += (V).x; N3[(U) >> 3][((U) >> 2) & 1][(U) & 3] += (V).x + (V).y; }
+#pragma unroll
+      for (int i = 0; i < UPC; ++i) {
+        switch (c * UPC + i) {   // wave-uniform; accumulator indices must be compile-time constants
+          case 0: BIEM_CADD3(0, cv[i]) break;   case 1: BIEM_CADD3(1, cv[i]) break;
+          case 2: BIEM_CADD3(2, cv[i]) break;   case 3: BIEM_CADD3(3, cv[i]) break;
+          case 4: BIEM_CADD3(4, cv[i]) break;   case 5: BIEM_CADD3(5, cv[i]) break;
+          case 6: BIEM_CADD3(6, cv[i]) break;   case 7: BIEM_CADD3(7, cv[i]) break;
+          case 8: BIEM_CADD3(8, cv[i]) break;   case 9: BIEM_CADD3(9, cv[i]) break;
+          case 10: BIEM_CADD3(10, cv[i]) break; case 11: BIEM_CADD3(11, cv[i]) break;
+          case 12: BIEM_CADD3(12, cv[i]) break; case 13: BIEM_CADD3(13, cv[i]) break;
+          case 14: BIEM_CADD3(14, cv[i]) break; default: BIEM_CADD3(15, cv[i]) break;
+        }
+      }
+#undef BIEM_CADD3
+      st = st == 2 ? 0 : st + 1;
+      if (c == 1) stores_pending = 0;
+    }
+    // tile finished: Cr' = N1 + P2, Ci' = N3 - N1 + P2; plain stores stay in flight while the next tile starts
+    cplx* Cs = A + (size_t)cs * sys_stride;
+    const int row0 = tg.row_begin + cty * BM3, col0 = tg.col_begin + ctx * BN3;
+    const bool full = row0 + BM3 <= n_pad && col0 + BN3 <= n_cols;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int col = col0 + wn * 32 + n * 16 + l15;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = row0 + wm * 32 + tm * 16 + 4 * g + l4;
+          const cplx v = make_double2(N1[tm][n][g] + P2[tm][n][g], N3[tm][n][g] - N1[tm][n][g] + P2[tm][n][g]);
+          if (full) Cs[(size_t)row * lda + col] = v;
+          else if (col < n_cols && row < n_pad) Cs[(size_t)row * lda + col] = v;
+          N1[tm][n][g] = 0.0; P2[tm][n][g] = 0.0; N3[tm][n][g] = 0.0;
+        }
+      }
+    }
+    if (tn_ < 0) break;
+    stores_pending = full ? 1 : 2;
+    cs = ns; cty = nty; ctx = ntx;
+  }
+}
+
 // C[row_begin:row_end, col_begin:col_end] -= P[0:kd]^T (rows of the region) * M[brow:brow+kd, cols of the region]
 static void launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, long long sys_stride, const cplx* Pw, long long ldp,
                                long long p_stride, int row_begin, int row_end, int col_begin, int col_end, int brow, int kd,
                                int prof_class = PK_GEMM, double prof_work = -1.0) {
   const int rrows = row_end - row_begin, rcols = col_end - col_begin;
   if (rrows <= 0 || rcols <= 0) return;
+  static const bool use4m = getenv("BIEM_GEMM_4M") != nullptr;   // A/B switch for the design notes; 3M is the product
+  const int bm = use4m ? BM2 : BM3, bn = use4m ? BN2 : BN3;
   TileGrid tg;
-  tg.ty_n = (rrows + BM2 - 1) / BM2; tg.tx_n = (rcols + BN2 - 1) / BN2;
+  tg.ty_n = (rrows + bm - 1) / bm; tg.tx_n = (rcols + bn - 1) / bn;
   tg.per_sys = tg.ty_n * tg.tx_n; tg.full_bands = tg.ty_n / 8; tg.ntiles = tg.per_sys * nb;
   tg.row_begin = row_begin; tg.row_end = row_end; tg.col_begin = col_begin; tg.col_end = col_end; tg.brow = brow;
-  int want = (tg.ntiles + 7) / 8 * 8;          // one workgroup per tile, capped at 2 per CU, multiple of 8
-  int grid = want < 512 ? want : 512;
+  static const bool use2stage = getenv("BIEM_GEMM_2STAGE") != nullptr;
+  const int cap = (use4m || !use2stage) ? 512 : 768;   // persistent grid: workgroups per CU x 256
+  int want = (tg.ntiles + 7) / 8 * 8;          // one workgroup per tile up to the cap, multiple of 8
+  int grid = want < cap ? want : cap;
   ProfScope ps(prof_class, st, prof_work >= 0.0 ? prof_work : 8.0 * (double)nb * rrows * (double)rcols * kd);
-  if (kd == 64)
-    hipLaunchKernelGGL(k_gemm_stream<64>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
-  else
-    hipLaunchKernelGGL(k_gemm_stream<128>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
+  if (use4m) {
+    if (kd == 64)
+      hipLaunchKernelGGL(k_gemm_stream<64>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
+    else
+      hipLaunchKernelGGL(k_gemm_stream<128>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
+  } else if (use2stage) {
+    if (kd == 64)
+      hipLaunchKernelGGL(k_gemm3m_stream<64>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
+    else
+      hipLaunchKernelGGL(k_gemm3m_stream<128>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
+  } else {
+    if (kd == 64)
+      hipLaunchKernelGGL(k_gemm3m_pipe<64>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
+    else
+      hipLaunchKernelGGL(k_gemm3m_pipe<128>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
+  }
 }
 
 // W = I - L11^{-1} for the unit-lower 64 x 64 diagonal block of a panel, stored [k][i] (the MFMA A-operand order), so that
@@ -673,6 +1124,7 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
   hipLaunchKernelGGL(k_zero_int, dim3((nb + 63) / 64), dim3(64), 0, st, d_info, nb);
   static bool inv_attr = false;
   if (!inv_attr) {
+
     BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_inv_l11, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * NB * NB * sizeof(cplx))));
     inv_attr = true;
   }
