@@ -382,6 +382,7 @@ struct TileGrid {
   int ty_n, tx_n, per_sys, full_bands, ntiles;
   int row_begin, row_end, col_begin, col_end;   // C region updated by this launch
   int brow;                                     // first row of the B operand (U12 rows brow .. brow + K)
+  int stagger_mode, stagger_sleep;              // experiment knobs (env BIEM_STAGGER / BIEM_STAGGER_SLEEP)
 };
 
 __device__ inline void tile_decode(const TileGrid& tg, int t, int& s, int& ty, int& tx) {
@@ -765,9 +766,14 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
   constexpr int NCH = KD / KC;               // 8 or 16 K-chunks per tile
   constexpr int UPC = 16 / NCH;              // C units (one complex per lane) per chunk: 2 or 1
   constexpr int NDMA = 4 + UPC;              // LDS-DMA instructions per wave per chunk
-  constexpr int STG = 2 * KC * 64 + UPC * 256;   // complex elements per stage
+  constexpr int AST = 68;                    // A row stride in LDS: +4 elements (64 B) so the broadcast A-fragment reads of
+                                             // two k-rows in one ds_read_b128 lane group hit different banks
+  constexpr int BOF = KC * AST;              // B block offset inside a stage
+  constexpr int COF = BOF + KC * 64;         // C-slice offset
+  constexpr int STG = COF + UPC * 256;       // complex elements per stage
   __shared__ cplx ring[3 * STG];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA bases (M0) and tile offsets stay on the SALU
   const int wm = wave >> 1, wn = wave & 1;
   const int l3 = lane & 3, l15 = lane & 15, l4 = lane >> 4;
   const int w = blockIdx.x, nblk = gridDim.x >> 3, xl = w & 7;
@@ -786,7 +792,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-  int cs, cty, ctx, ns = 0, nty = 0, ntx = 0;
+  int cs, cty, ctx;
   tile_decode(tg, t, cs, cty, ctx);
 
   const unsigned offA0 = (unsigned)(((size_t)(wave) * ldp + lane) * sizeof(cplx));
@@ -794,45 +800,67 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
   const unsigned offB0 = (unsigned)(((size_t)(wave) * lda + lane) * sizeof(cplx));
   const unsigned offB1 = (unsigned)(((size_t)(wave + 4) * lda + lane) * sizeof(cplx));
   const unsigned offC = (unsigned)(((size_t)(wm * 32 + l4) * lda + wn * 32 + l15) * sizeof(cplx));
-  // DMA group of chunk `ch` of tile (s_, ty_, tx_) into stage st: exactly NDMA instructions, all lanes active
-  auto issue = [&](int st, int s_, int ty_, int tx_, int ch) {
+  // Producer state: the DMA stream runs two chunks ahead of the multiplication and crosses tile boundaries on its own.
+  // Interior tiles use running scalar bases (pA, pB advance by a constant per chunk; pC = tile origin + a 16-entry
+  // pattern); edge tiles recompute clamped per-lane addresses (rare).
+  const long long strideA = (long long)KC * ldp * (long long)sizeof(cplx);
+  const long long strideB = (long long)KC * lda * (long long)sizeof(cplx);
+  int p_s = cs, p_ty = cty, p_tx = ctx, p_ch = 0;       // tile / chunk the next DMA group belongs to
+  bool p_interior = false, p_valid = true;
+  int p_tiles = 0, c_tiles = 0;                          // tiles started by the producer / finished by the consumer
+  const char *pA = nullptr, *pB = nullptr, *pC = nullptr;
+  auto producer_tile = [&]() {                             // (re)compute the bases for chunk 0 of tile (p_s, p_ty, p_tx)
+    const int r0 = tg.row_begin + p_ty * BM3, c0 = tg.col_begin + p_tx * BN3;
+    p_interior = r0 + BM3 <= n_pad && c0 + BN3 <= n_cols;
+    pA = (const char*)(Pw + ((size_t)p_s * p_stride + r0));
+    pB = (const char*)(A + ((size_t)p_s * sys_stride + (size_t)tg.brow * lda + c0));
+    pC = (const char*)(A + ((size_t)p_s * sys_stride + (size_t)r0 * lda + c0));
+    p_ch = 0;
+    ++p_tiles;
+  };
+  producer_tile();
+  // issue the DMA group of the producer's current chunk into stage st (exactly NDMA instructions, all lanes active), advance
+  auto issue = [&](int st) {
     cplx* S = ring + st * STG;
-    const int r0 = tg.row_begin + ty_ * BM3, c0 = tg.col_begin + tx_ * BN3;
-    const bool interior = r0 + BM3 <= n_pad && c0 + BN3 <= n_cols;      // wave-uniform
-    if (interior) {
-      const char* bA = (const char*)(Pw + ((size_t)s_ * p_stride + (size_t)(ch * KC) * ldp + r0));
-      const char* bB = (const char*)(A + ((size_t)s_ * sys_stride + (size_t)(tg.brow + ch * KC) * lda + c0));
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(bA + offA0), (lds_ptr_t)(S + wave * 64), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(bA + offA1), (lds_ptr_t)(S + (wave + 4) * 64), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(bB + offB0), (lds_ptr_t)(S + KC * 64 + wave * 64), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(bB + offB1), (lds_ptr_t)(S + KC * 64 + (wave + 4) * 64), 16, 0, 0);
+    if (p_interior) {
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(pA + offA0), (lds_ptr_t)(S + wave * AST), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(pA + offA1), (lds_ptr_t)(S + (wave + 4) * AST), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(pB + offB0), (lds_ptr_t)(S + BOF + wave * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(pB + offB1), (lds_ptr_t)(S + BOF + (wave + 4) * 64), 16, 0, 0);
 #pragma unroll
       for (int i = 0; i < UPC; ++i) {
-        const int u = ch * UPC + i;
-        const char* bC = (const char*)(A + ((size_t)s_ * sys_stride + (size_t)(r0 + (u >> 3) * 16 + 4 * (u & 3)) * lda + c0 + ((u >> 2) & 1) * 16));
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(bC + offC), (lds_ptr_t)(S + 2 * KC * 64 + i * 256 + wave * 64), 16, 0, 0);
+        const int u = p_ch * UPC + i;
+        const long long dC = ((long long)((u >> 3) * 16 + 4 * (u & 3)) * lda + ((u >> 2) & 1) * 16) * (long long)sizeof(cplx);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(pC + dC + offC), (lds_ptr_t)(S + COF + i * 256 + wave * 64), 16, 0, 0);
       }
-      return;
+    } else {
+      // edge tile: clamp instead of masking (the instruction count must stay uniform)
+      const cplx* Ps = Pw + (size_t)p_s * p_stride;
+      const cplx* As = A + (size_t)p_s * sys_stride;
+      const int r0 = tg.row_begin + p_ty * BM3, c0 = tg.col_begin + p_tx * BN3;
+      const int ar = min(r0 + lane, n_pad - 1), bc = min(c0 + lane, n_cols - 1);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ps + (size_t)(p_ch * KC + wave + 4 * r) * ldp + ar),
+                                         (lds_ptr_t)(S + (wave + 4 * r) * AST), 16, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(As + (size_t)(tg.brow + p_ch * KC + wave + 4 * r) * lda + bc),
+                                         (lds_ptr_t)(S + BOF + (wave + 4 * r) * 64), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < UPC; ++i) {
+        const int u = p_ch * UPC + i;
+        const int row = min(r0 + wm * 32 + (u >> 3) * 16 + 4 * (u & 3) + l4, n_pad - 1);
+        const int col = min(c0 + wn * 32 + ((u >> 2) & 1) * 16 + l15, n_cols - 1);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(As + (size_t)row * lda + col),
+                                         (lds_ptr_t)(S + COF + i * 256 + wave * 64), 16, 0, 0);
+      }
     }
-    // edge tile: clamp instead of masking (the instruction count must stay uniform)
-    const cplx* Ps = Pw + (size_t)s_ * p_stride;
-    const cplx* As = A + (size_t)s_ * sys_stride;
-    const int ar = min(r0 + lane, n_pad - 1), bc = min(c0 + lane, n_cols - 1);
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ps + (size_t)(ch * KC + wave + 4 * r) * ldp + ar),
-                                       (lds_ptr_t)(S + (wave + 4 * r) * 64), 16, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(As + (size_t)(tg.brow + ch * KC + wave + 4 * r) * lda + bc),
-                                       (lds_ptr_t)(S + KC * 64 + (wave + 4 * r) * 64), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < UPC; ++i) {
-      const int u = ch * UPC + i;
-      const int row = min(r0 + wm * 32 + (u >> 3) * 16 + 4 * (u & 3) + l4, n_pad - 1);
-      const int col = min(c0 + wn * 32 + ((u >> 2) & 1) * 16 + l15, n_cols - 1);
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(As + (size_t)row * lda + col),
-                                       (lds_ptr_t)(S + 2 * KC * 64 + i * 256 + wave * 64), 16, 0, 0);
+    pA += strideA; pB += strideB;
+    if (++p_ch == NCH) {                                   // producer moves on to the next tile of this workgroup
+      int tn = next_tile();
+      if (tn >= 0) { tile_decode(tg, tn, p_s, p_ty, p_tx); producer_tile(); }
+      else p_valid = false;
     }
   };
 
@@ -844,51 +872,51 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
 #pragma unroll
       for (int g = 0; g < 4; ++g) { N1[a][b][g] = 0.0; P2[a][b][g] = 0.0; N3[a][b][g] = 0.0; }
 
-  issue(0, cs, cty, ctx, 0);
-  issue(1, cs, cty, ctx, 1);
+  issue(0);
+  issue(1);
   int st = 0;                 // stage of the chunk about to be multiplied
   int stores_pending = 0;     // 0: none, 1: 16 stores of a full tile were issued after the groups in flight, 2: unknown count
   // per-lane LDS offsets of the fragments inside a stage (elements)
-  const int fbo = KC * 64 + l4 * 64 + wn * 32 + l15;      // + k4*256 + n*16
-  const int fao = l4 * 64 + wm * 32 + l3;                 // + k4*256 + tm*16 + 4g
+  const int fbo = BOF + l4 * 64 + wn * 32 + l15;          // + k4*4*64 + n*16
+  const int fao = l4 * AST + wm * 32 + l3;                // + k4*4*AST + tm*16 + 4g
+  // the producer is exactly one tile ahead whenever the consumer finishes a tile (it switches at the consumer's chunk
+  // NCH-3 and not again before chunk NCH-3 of the next tile): its current coordinates are the consumer's next tile
   for (;;) {
-    int tn_ = -2;
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
       // retire this chunk's DMA group (mine), then meet the other waves: their groups have landed too and nobody still
       // reads the stage the next group is about to overwrite
-      const bool last_group = (tn_ == -1) && (c == NCH - 1);
-      if (last_group || (stores_pending == 2 && c == 0)) wait_vmcnt<0>();
-      else if (stores_pending == 1 && c < 2) wait_vmcnt<NDMA + 16>();
-      else wait_vmcnt<NDMA>();
+      if (__builtin_expect(stores_pending == 0 && p_valid, 1)) {
+        wait_vmcnt<NDMA>();
+      } else if (!p_valid) {
+        wait_vmcnt<0>();                                   // tail of this workgroup's work: no further groups are issued
+      } else if (stores_pending == 2 && c == 0) {
+        wait_vmcnt<0>();
+      } else if (stores_pending == 1 && c < 2) {
+        wait_vmcnt<NDMA + 16>();
+      } else {
+        wait_vmcnt<NDMA>();
+      }
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       const int st2 = st >= 1 ? st - 1 : 2;            // (st + 2) % 3
-      if (c + 2 < NCH) {
-        issue(st2, cs, cty, ctx, c + 2);
-      } else {
-        if (c == NCH - 2) {
-          tn_ = next_tile();
-          if (tn_ >= 0) tile_decode(tg, tn_, ns, nty, ntx);
-        }
-        if (tn_ >= 0) issue(st2, ns, nty, ntx, c + 2 - NCH);
-      }
+      if (p_valid) issue(st2);
       const cplx* S = ring + st * STG;
       // fragments of both k4-steps and the C units of this chunk: 20 + UPC ds_read_b128 and their lgkmcnt wait in ONE asm
       // statement - hipcc may copy an asm output right after the statement, i.e. before a separate wait (that was the
-      // cause of percent-level errors in an earlier build); byte offsets: k4*4096 + tm*256 + g*64 (A), k4*4096 + n*256 (B)
+      // cause of percent-level errors in an earlier build); byte offsets: k4*4352 + tm*256 + g*64 (A), k4*4096 + n*256 (B)
       cplx fb[2][2], fa[2][2][4], cv[UPC];
       {
         const unsigned aA = (unsigned)(size_t)(const __attribute__((address_space(3))) cplx*)(S + fao);
         const unsigned aB = (unsigned)(size_t)(const __attribute__((address_space(3))) cplx*)(S + fbo);
-        const unsigned aC = (unsigned)(size_t)(const __attribute__((address_space(3))) cplx*)(S + 2 * KC * 64 + tid);
+        const unsigned aC = (unsigned)(size_t)(const __attribute__((address_space(3))) cplx*)(S + COF + tid);
         if constexpr (UPC == 1) {
           asm volatile(
               "ds_read_b128 %16, %22\n\tds_read_b128 %17, %22 offset:256\n\tds_read_b128 %18, %22 offset:4096\n\tds_read_b128 %19, %22 offset:4352\n\t"
               "ds_read_b128 %0, %21\n\tds_read_b128 %1, %21 offset:64\n\tds_read_b128 %2, %21 offset:128\n\tds_read_b128 %3, %21 offset:192\n\t"
               "ds_read_b128 %4, %21 offset:256\n\tds_read_b128 %5, %21 offset:320\n\tds_read_b128 %6, %21 offset:384\n\tds_read_b128 %7, %21 offset:448\n\t"
-              "ds_read_b128 %8, %21 offset:4096\n\tds_read_b128 %9, %21 offset:4160\n\tds_read_b128 %10, %21 offset:4224\n\tds_read_b128 %11, %21 offset:4288\n\t"
-              "ds_read_b128 %12, %21 offset:4352\n\tds_read_b128 %13, %21 offset:4416\n\tds_read_b128 %14, %21 offset:4480\n\tds_read_b128 %15, %21 offset:4544\n\t"
+              "ds_read_b128 %8, %21 offset:4352\n\tds_read_b128 %9, %21 offset:4416\n\tds_read_b128 %10, %21 offset:4480\n\tds_read_b128 %11, %21 offset:4544\n\t"
+              "ds_read_b128 %12, %21 offset:4608\n\tds_read_b128 %13, %21 offset:4672\n\tds_read_b128 %14, %21 offset:4736\n\tds_read_b128 %15, %21 offset:4800\n\t"
               "ds_read_b128 %20, %23\n\t"
               "s_waitcnt lgkmcnt(0)"
               : "=&v"(fa[0][0][0]), "=&v"(fa[0][0][1]), "=&v"(fa[0][0][2]), "=&v"(fa[0][0][3]), "=&v"(fa[0][1][0]), "=&v"(fa[0][1][1]),
@@ -902,8 +930,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
               "ds_read_b128 %16, %23\n\tds_read_b128 %17, %23 offset:256\n\tds_read_b128 %18, %23 offset:4096\n\tds_read_b128 %19, %23 offset:4352\n\t"
               "ds_read_b128 %0, %22\n\tds_read_b128 %1, %22 offset:64\n\tds_read_b128 %2, %22 offset:128\n\tds_read_b128 %3, %22 offset:192\n\t"
               "ds_read_b128 %4, %22 offset:256\n\tds_read_b128 %5, %22 offset:320\n\tds_read_b128 %6, %22 offset:384\n\tds_read_b128 %7, %22 offset:448\n\t"
-              "ds_read_b128 %8, %22 offset:4096\n\tds_read_b128 %9, %22 offset:4160\n\tds_read_b128 %10, %22 offset:4224\n\tds_read_b128 %11, %22 offset:4288\n\t"
-              "ds_read_b128 %12, %22 offset:4352\n\tds_read_b128 %13, %22 offset:4416\n\tds_read_b128 %14, %22 offset:4480\n\tds_read_b128 %15, %22 offset:4544\n\t"
+              "ds_read_b128 %8, %22 offset:4352\n\tds_read_b128 %9, %22 offset:4416\n\tds_read_b128 %10, %22 offset:4480\n\tds_read_b128 %11, %22 offset:4544\n\t"
+              "ds_read_b128 %12, %22 offset:4608\n\tds_read_b128 %13, %22 offset:4672\n\tds_read_b128 %14, %22 offset:4736\n\tds_read_b128 %15, %22 offset:4800\n\t"
               "ds_read_b128 %20, %24\n\tds_read_b128 %21, %24 offset:4096\n\t"
               "s_waitcnt lgkmcnt(0)"
               : "=&v"(fa[0][0][0]), "=&v"(fa[0][0][1]), "=&v"(fa[0][0][2]), "=&v"(fa[0][0][3]), "=&v"(fa[0][1][0]), "=&v"(fa[0][1][1]),
@@ -984,9 +1012,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
         }
       }
     }
-    if (tn_ < 0) break;
+    if (++c_tiles == p_tiles) break;                     // the producer started no further tile: done
     stores_pending = full ? 1 : 2;
-    cs = ns; cty = nty; ctx = ntx;
+    cs = p_s; cty = p_ty; ctx = p_tx;
   }
 }
 
@@ -1003,7 +1031,11 @@ static void launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, l
   tg.per_sys = tg.ty_n * tg.tx_n; tg.full_bands = tg.ty_n / 8; tg.ntiles = tg.per_sys * nb;
   tg.row_begin = row_begin; tg.row_end = row_end; tg.col_begin = col_begin; tg.col_end = col_end; tg.brow = brow;
   static const bool use2stage = getenv("BIEM_GEMM_2STAGE") != nullptr;
-  const int cap = (use4m || !use2stage) ? 512 : 768;   // persistent grid: workgroups per CU x 256
+  static const int grid_cap_env = getenv("BIEM_GEMM_GRID") ? atoi(getenv("BIEM_GEMM_GRID")) : 0;
+  static const int stagger_mode = getenv("BIEM_STAGGER") ? atoi(getenv("BIEM_STAGGER")) : 0;
+  static const int stagger_sleep = getenv("BIEM_STAGGER_SLEEP") ? atoi(getenv("BIEM_STAGGER_SLEEP")) : 3;
+  tg.stagger_mode = stagger_mode; tg.stagger_sleep = stagger_sleep;
+  const int cap = grid_cap_env > 0 ? grid_cap_env : ((use4m || !use2stage) ? 512 : 768);   // persistent grid: workgroups per CU x 256
   int want = (tg.ntiles + 7) / 8 * 8;          // one workgroup per tile up to the cap, multiple of 8
   int grid = want < cap ? want : cap;
   ProfScope ps(prof_class, st, prof_work >= 0.0 ? prof_work : 8.0 * (double)nb * rrows * (double)rcols * kd);
