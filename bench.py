@@ -161,6 +161,14 @@ def main():
         cpu = {"value": 1.0 / cpu_dt, "unit": "systems/s", "cores": int(threads), "kind": "port",
                "sample": f"1 system of the workload (k={w['ks'][0]:.4g}), oracle fill + numpy.linalg.solve, {cpu_dt:.1f} s"}
 
+    # HBM traffic of the dominant kernel per launch: measured once with rocprofv3 PMC passes (cannot run inside bench.py);
+    # bytes per launch per system from the committed summary, scaled to this run's systems per launch
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+    if os.path.exists(tpath) and args.n_end == 20:
+        with open(tpath) as f:
+            traffic = json.load(f)["bytes_per_launch_per_system"] * per_gpu
+
     out = {
         "metric": "BIEM systems solved/sec + max |u_scat| rel-err vs NumPy ref",
         "value": value,
@@ -179,10 +187,10 @@ def main():
                    "systems_per_gpu": per_gpu, "parallelism": f"batch-shard x{world}"},
         "max_rel_err_uscat": relerr,
         "roofline": {
-            "bound": "mfma", "kernel": "k_gemm (zgemm trailing update, v_mfma_f64_16x16x4_f64)",
+            "bound": "mfma", "kernel": "k_gemm3m_pipe<128> (zgemm3m trailing update, v_mfma_f64_4x4x4_4b_f64)",
             "achieved": gemm_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": (gemm_tflops / FP64_MFMA_PEAK_TFLOPS) if gemm_tflops else None,
-            "traffic": None,
+            "traffic": traffic,
             "avg_launch_ms": ms[gi] / launches[gi] if launches[gi] else None,
             "lu_effective_tflops": lu_flops * per_gpu * args.steps / (sum(ms[3:8]) * 1e-3) / 1e12 if sum(ms[3:8]) > 0 else None,
         },
