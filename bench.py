@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X FP64 matrix, vendor spec (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
-CLASSES = ["tables", "fill", "rhs", "panel", "swap", "trsm", "gemm", "back", "other"]
+CLASSES = ["tables", "fill", "rhs", "panel", "swap", "trsm", "gemm", "back", "gemm_k64"]
 
 
 def workload(n_sys_total: int, rank: int, world: int, per_gpu: int, dev):
@@ -192,7 +192,7 @@ def main():
             "frac": (gemm_tflops / FP64_MFMA_PEAK_TFLOPS) if gemm_tflops else None,
             "traffic": traffic,
             "avg_launch_ms": ms[gi] / launches[gi] if launches[gi] else None,
-            "lu_effective_tflops": lu_flops * per_gpu * args.steps / (sum(ms[3:8]) * 1e-3) / 1e12 if sum(ms[3:8]) > 0 else None,
+            "lu_effective_tflops": lu_flops * per_gpu * args.steps / (sum(ms[3:9]) * 1e-3) / 1e12 if sum(ms[3:9]) > 0 else None,
         },
         "fill": {"bound": "hbm", "achieved": fill_gbs, "peak": 8000.0, "unit": "GB/s", "frac": fill_gbs / 8000.0 if fill_gbs else None},
         "stage_ms_per_step": {n: m / args.steps for n, m in zip(CLASSES, ms)},

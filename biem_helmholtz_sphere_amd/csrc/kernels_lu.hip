@@ -382,7 +382,6 @@ struct TileGrid {
   int ty_n, tx_n, per_sys, full_bands, ntiles;
   int row_begin, row_end, col_begin, col_end;   // C region updated by this launch
   int brow;                                     // first row of the B operand (U12 rows brow .. brow + K)
-  int stagger_mode, stagger_sleep;              // experiment knobs (env BIEM_STAGGER / BIEM_STAGGER_SLEEP)
 };
 
 __device__ inline void tile_decode(const TileGrid& tg, int t, int& s, int& ty, int& tx) {
@@ -955,6 +954,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
           for (int g = 0; g < 4; ++g) fas[k4][tm][g] = fa[k4][tm][g].x + fa[k4][tm][g].y;
       }
       mfma_fence();
+      // the MFMA block runs at low priority, everything else at high: the SIMD partner's barrier / DMA / fragment-read
+      // phase then slips between this wave's MFMAs (which need 4 of every 16 issue cycles): +2-3 % measured.  Delaying one
+      // of the two resident workgroups by half a chunk, or issuing the DMA group between the two k4 halves, changed nothing.
+      __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int k4 = 0; k4 < 2; ++k4) {
 #pragma unroll
@@ -974,6 +977,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
         }
       }
       mfma_fence();
+      __builtin_amdgcn_s_setprio(3);
       // this chunk's C units (u = c*UPC + i -> sub-tile (u>>3, (u>>2)&1), register u&3) join their accumulators
 #define BIEM_CADD3(U, V) { N1[(U) >> 3][((U) >> 2) & 1][(U) & 3] += (V).x; N3[(U) >> 3][((U) >> 2) & 1][(U) & 3] += (V).x + (V).y; }
 #pragma unroll
@@ -1031,11 +1035,7 @@ static void launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, l
   tg.per_sys = tg.ty_n * tg.tx_n; tg.full_bands = tg.ty_n / 8; tg.ntiles = tg.per_sys * nb;
   tg.row_begin = row_begin; tg.row_end = row_end; tg.col_begin = col_begin; tg.col_end = col_end; tg.brow = brow;
   static const bool use2stage = getenv("BIEM_GEMM_2STAGE") != nullptr;
-  static const int grid_cap_env = getenv("BIEM_GEMM_GRID") ? atoi(getenv("BIEM_GEMM_GRID")) : 0;
-  static const int stagger_mode = getenv("BIEM_STAGGER") ? atoi(getenv("BIEM_STAGGER")) : 0;
-  static const int stagger_sleep = getenv("BIEM_STAGGER_SLEEP") ? atoi(getenv("BIEM_STAGGER_SLEEP")) : 3;
-  tg.stagger_mode = stagger_mode; tg.stagger_sleep = stagger_sleep;
-  const int cap = grid_cap_env > 0 ? grid_cap_env : ((use4m || !use2stage) ? 512 : 768);   // persistent grid: workgroups per CU x 256
+  const int cap = (use4m || !use2stage) ? 512 : 768;   // persistent grid: workgroups per CU x 256
   int want = (tg.ntiles + 7) / 8 * 8;          // one workgroup per tile up to the cap, multiple of 8
   int grid = want < cap ? want : cap;
   ProfScope ps(prof_class, st, prof_work >= 0.0 ? prof_work : 8.0 * (double)nb * rrows * (double)rcols * kd);
@@ -1223,9 +1223,9 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     for (int J = 0; J < n_pad; J += 2 * NB) {
       panel(J, 0); swap_right(J); trsm(J, 0);
       if (J + NB >= n_pad) break;                        // odd tail: nothing below the panel, forward elimination done
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + NB, n_pad, J + NB, J + 2 * NB, J, NB);
+      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + NB, n_pad, J + NB, J + 2 * NB, J, NB, PK_OTHER);
       panel(J + NB, NB); swap_right(J + NB);
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + NB, J + 2 * NB, J + 2 * NB, n_cols, J, NB);
+      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + NB, J + 2 * NB, J + 2 * NB, n_cols, J, NB, PK_OTHER);
       trsm(J + NB, NB);
       launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 2 * NB, n_pad, J + 2 * NB, n_cols, J, 2 * NB);
     }
