@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from ._coords import SphericalCoordinates, harm_count, n_end_from_harm
+from ._coords import SphericalCoordinates, canonical_tree, harm_count, n_end_from_harm
 
 try:  # numpy >= 1.25
     from numpy.exceptions import ComplexWarning
@@ -498,14 +498,19 @@ def _flatten(batch, B, centers_t, radii_t, k_t, eta_t, alpha_t, beta_t) -> _Flat
     return _Flat(nb, B, kf, ef, cf, rf, int(geom_b), af, bf, int(ab_b))
 
 
-def _boundary_samples(plan: _Plan, origin: _Origin, fl: _Flat, batch, uin, uin_grad) -> torch.Tensor:
-    """g[nb, B, Q] = (-alpha u_in - beta d_n u_in)(c_b + rho_b y_q): the closure `f` of reference :611-624."""
+def _boundary_samples(plan: _Plan, origin: _Origin, fl: _Flat, batch, uin, uin_grad, perm) -> torch.Tensor:
+    """g[nb, B, Q] = (-alpha u_in - beta d_n u_in)(c_b + rho_b y_q): the closure `f` of reference :611-624.
+
+    fl.centers are in the plan's canonical axes; the user's callables see ORIGINAL axes (x_orig[perm[i]] = x_canon[i])."""
     dev, d, Q, B, nb = plan.dev, plan.d, plan.Q, fl.B, fl.nb
     qshape = plan.quad_shape()
     nbt = len(batch)
-    y = plan.quad_y.T.reshape((d,) + qshape)                           # (d, ...(f))
+    inv = [0] * d
+    for i, pi_ in enumerate(perm):
+        inv[pi_] = i
+    y = plan.quad_y.T[inv].reshape((d,) + qshape)                      # (d, ...(f)), original axes
     x_rel = y[(...,) + (None,) * (nbt + 1)]                            # (d, ...(f), 1.., 1)
-    cen = fl.centers.reshape(((nb,) if fl.geom_batched else (1,)) + (B, d))
+    cen = fl.centers[..., inv].reshape(((nb,) if fl.geom_batched else (1,)) + (B, d))
     rad = fl.radii.reshape(((nb,) if fl.geom_batched else (1,)) + (B,))
     if fl.geom_batched:
         cen = cen.reshape(tuple(batch) + (B, d))
@@ -570,13 +575,14 @@ def biem(
     if translational_coefficients_method not in (None, "gumerov", "plane_wave", "triplet"):
         raise ValueError(f"Invalid translational_coefficients_method: {translational_coefficients_method}")
     origin, dev, batch, centers_t, radii_t, k_t, eta_t, alpha_t, beta_t = _check_biem_inputs(c, centers, radii, k, eta, alpha, beta)
-    tree = c.branching_types_expression_str
+    # trees with primed nodes run as their canonical tree in permuted axes (canonical component i = original perm[i])
+    tree, perm = canonical_tree(c.branching_types_expression_str)
     lib = L.load()
     B = int(radii_t.shape[-1])
     ndim_first = k_t.ndim
     plan = _plan(tree, n_end, dev)
     H, Q = plan.H, plan.Q
-    fl = _flatten(batch, B, centers_t, radii_t, k_t, eta_t, alpha_t, beta_t)
+    fl = _flatten(batch, B, centers_t[..., list(perm)], radii_t, k_t, eta_t, alpha_t, beta_t)
     nb = fl.nb
     sp = _stream_ptr(dev)
 
@@ -587,7 +593,7 @@ def biem(
             raise ValueError("alpha is not zero, but uin is None. uin must be provided to compute the boundary condition.")
         if not bool(torch.all(beta_t == 0)) and uin_grad is None:
             raise ValueError("beta is not zero, but uin_grad is None. uin_grad must be provided to compute the boundary condition.")
-        g = _boundary_samples(plan, origin, fl, batch, uin, uin_grad)
+        g = _boundary_samples(plan, origin, fl, batch, uin, uin_grad, perm)
 
     use_matrix = (not has_rhs) or B > 1 or force_matrix          # reference :643-645
     density_t = None
@@ -660,7 +666,7 @@ def biem_u(res: Any, x: Array, /, far_field: bool = False, per_ball: bool = Fals
     if res.kind not in ("outer", "inner"):
         raise ValueError(f"Invalid kind: {res.kind}")
     c = res.c
-    tree = c.branching_types_expression_str
+    tree, perm = canonical_tree(c.branching_types_expression_str)
     origin, dev = _origin_of(res.centers, res.radii, res.k, res.density, x)
     if isinstance(res.density, torch.Tensor) and res.density.dtype == torch.complex64:
         origin.real_dtype = torch.float32
@@ -670,7 +676,7 @@ def biem_u(res: Any, x: Array, /, far_field: bool = False, per_ball: bool = Fals
     f64 = torch.float64
     k_t = _to_dev(res.k, dev, f64)
     eta_t = _to_dev(res.eta, dev, f64)
-    cen_t = _to_dev(res.centers, dev, f64)          # [d, ...(first), B]
+    cen_t = _to_dev(res.centers, dev, f64)[list(perm)]   # [d, ...(first), B], canonical axes
     rad_t = _to_dev(res.radii, dev, f64)            # [...(first), B]
     dens_t = _to_dev(res.density, dev, torch.complex128)
     d = c.c_ndim
@@ -688,6 +694,7 @@ def biem_u(res: Any, x: Array, /, far_field: bool = False, per_ball: bool = Fals
     x_t = _to_dev(x, dev, f64)
     if x_t.shape[0] != d:
         raise ValueError(f"x must have shape ({d}, ...), got {tuple(x_t.shape)}")
+    x_t = x_t[list(perm)]
     if expand_x:
         xshape = tuple(x_t.shape[1:])
         pts = x_t.reshape(d, -1).contiguous()

@@ -8,15 +8,30 @@ committed ``a.svg / ba.svg / bba.svg``:
     a   : x0 = r cos t0,  x1 = r sin t0
     ba  : x0 = r cos t0,  x1 = r sin t0 cos t1,  x2 = r sin t0 sin t1
     bba : x0 = r cos t0,  x1 = r sin t0 cos t1,  x2 = r sin t0 sin t1 cos t2,  x3 = r sin t0 sin t1 sin t2
+    bpa, bpbpa : primed polar nodes measure the angle from the equator (t in [-pi/2, pi/2]); see CANONICAL below
 
 Works on torch tensors and NumPy arrays alike (only elementwise maths is used).
 """
 from __future__ import annotations
 
+import math
 from typing import Any, Mapping
 
-SUPPORTED = {"a": 2, "ba": 3, "bba": 4}
-NEXT = ("bpa", "bpbpa", "caa")  # SURVEY 8(f) item 3: not built yet
+SUPPORTED = {"a": 2, "ba": 3, "bba": 4, "bpa": 3, "bpbpa": 4}
+NEXT = ("caa",)  # SURVEY 8(f) item 3: not built yet
+# Trees with primed (b') nodes, in the axis convention of the reference's committed bpa.svg / bpbpa.svg (its jascome driver
+# relabels node 0 <-> d-1 first, cli.py:65-69): they are ba / bba in permuted Cartesian axes, canonical y_i = x_{perm[i]}:
+#   bpa   : x2 = r sin t0, x1 = r cos t0 cos t1, x0 = r cos t0 sin t1                      -> (y0, y1, y2) = (x2, x1, x0)
+#   bpbpa : x3 = r sin t0, x1 = r cos t0 sin t1, x2 = r cos t0 cos t1 cos t2, x0 = .. sin t2 -> (y0..y3) = (x3, x1, x2, x0)
+# (pinned by the jascome goldens through the oracle and the GPU path: tests/test_oracle_golden.py, tests/test_gpu_parity.py)
+CANONICAL = {"bpa": ("ba", (2, 1, 0)), "bpbpa": ("bba", (3, 1, 2, 0))}
+
+
+def canonical_tree(branching_types: str):
+    """(canonical tree name, perm) with canonical component i = original component perm[i]; identity for a / ba / bba."""
+    if branching_types in CANONICAL:
+        return CANONICAL[branching_types]
+    return branching_types, tuple(range(SUPPORTED[branching_types]))
 
 
 def _xp(a: Any):
@@ -63,6 +78,21 @@ class SphericalCoordinates:
         """{"r": r (optional, default 1), 0: theta0, 1: theta1, ...} -> cartesian (stacked on axis 0 if as_array)."""
         th = [spherical[i] for i in range(self.s_ndim)]
         xp = _xp(th[0])
+        if self.branching_types_expression_str in CANONICAL:
+            # b' angle t (from the equator) = pi/2 - colatitude of the canonical tree, for every polar node
+            base, perm = CANONICAL[self.branching_types_expression_str]
+            sph = {i: (math.pi / 2 - th[i]) for i in range(self.s_ndim - 1)}
+            sph[self.s_ndim - 1] = th[-1]
+            if "r" in spherical:
+                sph["r"] = spherical["r"]
+            y = SphericalCoordinates(base).to_cartesian(sph, as_array=False)
+            comps = [None] * self.c_ndim
+            for i, pi_ in enumerate(perm):
+                comps[pi_] = y[i]
+            if as_array:
+                comps = xp.broadcast_arrays(*comps) if xp.__name__ == "numpy" else xp.broadcast_tensors(*comps)
+                return xp.stack(list(comps), 0)
+            return {i: c for i, c in enumerate(comps)}
         r = spherical["r"] if "r" in spherical else None
         comps = []
         sin_prod = None
@@ -82,6 +112,13 @@ class SphericalCoordinates:
         """cartesian x[d, ...] (array or mapping 0..d-1) -> {"r": r, 0: theta0, ...}; polar angles in [0, pi], last in (-pi, pi]."""
         xs = [x[i] for i in range(self.c_ndim)]
         xp = _xp(xs[0])
+        if self.branching_types_expression_str in CANONICAL:
+            base, perm = CANONICAL[self.branching_types_expression_str]
+            sph = SphericalCoordinates(base).from_cartesian([xs[pi_] for pi_ in perm])
+            out = {"r": sph["r"], self.s_ndim - 1: sph[self.s_ndim - 1]}
+            for i in range(self.s_ndim - 1):
+                out[i] = math.pi / 2 - sph[i]
+            return out
         out = {}
         # tail norms: rho_i = |(x_i, ..., x_{d-1})|
         tail = xs[-1] * xs[-1]
@@ -105,6 +142,7 @@ def harm_count(branching_types: str, n_end: int) -> int:
     """Number of harmonics of degree < n_end (``ush.harm_n_ndim_le``)."""
     if n_end <= 0:
         return 0
+    branching_types = CANONICAL.get(branching_types, (branching_types,))[0]
     if branching_types == "a":
         return 2 * n_end - 1
     if branching_types == "ba":

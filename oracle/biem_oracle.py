@@ -39,6 +39,8 @@ un-vendored ``ush.flatten_harmonics``):
     a   : m = 0, 1, .., n_end-1, -(n_end-1), .., -1           (degree n = |m|)
     ba  : (n, m), n-major, m = -n..n                          index n^2 + n + m
     bba : (n, l, m), n-major, then l = 0..n, then m = -l..l
+    bpa / bpbpa : as ba / bba in the permuted axes (x2, x1, x0) / (x3, x1, x2, x0) of the committed bpa.svg / bpbpa.svg
+                  (the trees of the reference's jascome driver after its node relabel, cli.py:65-69)
 """
 from __future__ import annotations
 
@@ -143,10 +145,23 @@ def _gauss_cheb2(n):
 class Tree:
     name: str
     d: int
+    base: str = ""            # trees with primed nodes are a base tree in permuted Cartesian axes:
+    perm: tuple = ()          #   canonical y_i = x_{perm[i]}   (bpa: (x2, x1, x0) is `ba`; bpbpa: (x3, x1, x2, x0) is `bba`)
+
+    def _canon(self):
+        return _TREES[self.base] if self.base else self
+
+    def _inv(self):
+        inv = [0] * self.d
+        for i, pi in enumerate(self.perm):
+            inv[pi] = i
+        return inv
 
     # ---- index sets -------------------------------------------------------------------
     def index(self, n_end: int):
         """List of harmonic labels of degree < n_end in this project's canonical order."""
+        if self.base:
+            return self._canon().index(n_end)
         if self.name == "a":
             return [(m,) for m in list(range(0, n_end)) + list(range(-(n_end - 1), 0))]
         if self.name == "ba":
@@ -156,6 +171,8 @@ class Tree:
         raise NotImplementedError(self.name)
 
     def degrees(self, n_end: int) -> np.ndarray:
+        if self.base:
+            return self._canon().degrees(n_end)
         if self.name == "a":
             return np.array([abs(t[0]) for t in self.index(n_end)])
         return np.array([t[0] for t in self.index(n_end)])
@@ -167,6 +184,8 @@ class Tree:
     def harmonics(self, u: np.ndarray, n_end: int) -> np.ndarray:
         """Y[h, P] at unit vectors u[P, d] for all labels of degree < n_end."""
         u = np.asarray(u, dtype=np.float64)
+        if self.base:
+            return self._canon().harmonics(u[:, list(self.perm)], n_end)
         idx = self.index(n_end)
         P = u.shape[0]
         out = np.zeros((len(idx), P), dtype=np.complex128)
@@ -199,6 +218,9 @@ class Tree:
     # ---- quadrature (the rule ush.expand(n=n_end) uses) -------------------------
     def quadrature(self, n: int):
         """Unit vectors y[Q, d] and weights w[Q] of the n-rule (tensor Gauss)."""
+        if self.base:
+            y, w = self._canon().quadrature(n)
+            return y[:, self._inv()], w
         phi = np.arange(2 * n) * (math.pi / n)
         wphi = np.full(2 * n, math.pi / n)
         if self.name == "a":
@@ -222,7 +244,8 @@ class Tree:
         raise NotImplementedError(self.name)
 
 
-_TREES = {"a": Tree("a", 2), "ba": Tree("ba", 3), "bba": Tree("bba", 4)}
+_TREES = {"a": Tree("a", 2), "ba": Tree("ba", 3), "bba": Tree("bba", 4),
+          "bpa": Tree("bpa", 3, "ba", (2, 1, 0)), "bpbpa": Tree("bpbpa", 4, "bba", (3, 1, 2, 0))}
 
 
 def tree(name: str) -> Tree:
@@ -350,6 +373,8 @@ def translation_SR(tr: Tree, n_end: int, k: float, t: np.ndarray) -> np.ndarray:
     Exact closed form of SURVEY A.5 with pre-tabulated triple integrals.
     """
     t = np.asarray(t, dtype=np.float64)
+    if tr.base:
+        return translation_SR(tr._canon(), n_end, k, t[list(tr.perm)])
     d = tr.d
     r = float(np.linalg.norm(t))
     if tr.name == "a":

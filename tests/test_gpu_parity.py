@@ -267,7 +267,7 @@ def test_golden_rows_through_gpu(amd, golden_dir):
     with open(os.path.join(golden_dir, "jascome_output.csv")) as f:
         for r in csv.DictReader(f):
             bt, n_end = r["branching_types"], int(r["n_end"])
-            if bt in ("a", "ba", "bba") and n_end <= 6:
+            if bt in ("a", "ba", "bba", "bpa", "bpbpa") and n_end <= 6:
                 tol = 2e-12 if n_end == 6 else 1e-12        # triplet drift of the reference itself at n_end = 6
                 assert abs(run(bt, n_end, 1.0, O.grid_centers(0, O.tree(bt).d)) - complex(r["uscat"])) < tol, (bt, n_end)
                 n += 1
@@ -285,7 +285,7 @@ def test_golden_rows_through_gpu(amd, golden_dir):
             if nbal in half and n_end in (3, 13, 32, 64) and nbal * (2 * n_end - 1) <= 2100:
                 assert abs(run("a", n_end, 1.0, O.grid_centers(half[nbal], 2)) - complex(r["uscat"])) < 1e-11, (nbal, n_end)
                 n += 1
-    assert n > 40
+    assert n > 52
 
 
 def test_batch_of_wavenumbers_matches_one_by_one(amd):
@@ -311,3 +311,71 @@ def test_mfma_f64_rate_is_reported(lib):
     L.check(l.biem_bench_mfma_f64(20000, C.byref(t), None))
     print("v_mfma_f64_16x16x4_f64 issue-rate microbenchmark: %.1f TFLOP/s" % t.value)
     assert 20.0 < t.value < 200.0
+
+
+# ---------------------------------------------------------------------------- wider API surface
+def test_sweep_driver_reproduces_reference_csv(amd, golden_dir, tmp_path):
+    """The jascome-style sweep writes the reference's schema and its values match the committed file (n_end <= 5)."""
+    from biem_helmholtz_sphere_amd import sweep
+
+    out = tmp_path / "jascome_output.csv"
+    sweep.main(["jascome", "--out", str(out), "--types", "a,ba,bpa,bba,bpbpa", "--n-end-max", "5"])
+    with open(out) as f:
+        mine = {(r["branching_types"], int(r["n_end"])): complex(r["uscat"]) for r in csv.DictReader(f)}
+    with open(os.path.join(golden_dir, "jascome_output.csv")) as f:
+        hdr = f.readline()
+    assert open(out).readline() == hdr
+    n = 0
+    with open(os.path.join(golden_dir, "jascome_output.csv")) as f:
+        for r in csv.DictReader(f):
+            key = (r["branching_types"], int(r["n_end"]))
+            if key in mine:
+                assert abs(mine[key] - complex(r["uscat"])) < 1e-12, key
+                n += 1
+    assert n == 25
+
+
+def test_point_source_incident_field(amd):
+    """point_source (reference :391-450): incident field h_n(k |x - s|) through the HIP radial kernel; vs the oracle."""
+    k, src, n = 1.3, np.array([0.5, -4.0, 1.0]), 1
+    cen = np.array([[0.0, 1.5, 0.0], [0.2, -1.4, 0.3]])
+    rad = np.array([0.9, 0.7])
+    uo, go = O.point_source(k, src, n)
+    res = O.solve_biem("ba", centers=cen, radii=rad, k=k, n_end=7, alpha=1.0, beta=0.3, uin=uo, uin_grad=go)
+    x = np.array([[3.0, 0.0, 0.5], [0.0, 0.0, 4.0]])
+    ref = O.uscat(res, x)
+    c = amd.create_from_branching_types("ba")
+    uin, ugr = amd.point_source(k=_dev(k), source=_dev(src), n=n)
+    calc = amd.biem(c, centers=_dev(cen), radii=_dev(rad), k=_dev(k), n_end=7, alpha=1.0, beta=0.3, uin=uin, uin_grad=ugr)
+    u = calc.uscat(_dev(x.T)).cpu().numpy()
+    assert np.max(np.abs(u - ref) / np.abs(ref)) < 1e-10
+
+
+def test_float32_inputs_and_per_ball_alpha_beta_batch(amd):
+    """float32 arrays (reference tests/conftest.py:54-56) give complex64 results; per-ball alpha/beta with a k batch."""
+    c = amd.create_from_branching_types("a")
+    cen = np.array([[0.0, 2.0], [0.0, -2.0], [4.0, 0.5]])
+    rad = np.array([1.0, 0.8, 0.5])
+    ks = np.array([0.7, 1.9])
+    alpha = np.array([[1.0, 0.0, 1.0 + 0.5j], [1.0, 0.0, 1.0 + 0.5j]])
+    beta = np.array([[0.0, 1.0, 0.2], [0.0, 1.0, 0.2]])
+    dirs = np.tile(np.array([[1.0], [0.4]]), (1, 2))
+    uin, ugr = amd.plane_wave(k=_dev(ks), direction=_dev(dirs))
+    calc = amd.biem(c, centers=_dev(cen)[None], radii=_dev(rad)[None], k=_dev(ks), n_end=9, alpha=_dev(alpha, torch.complex128),
+                    beta=_dev(beta, torch.complex128), uin=uin, uin_grad=ugr)
+    x = np.array([[6.0, 1.0], [-3.0, 0.0]])
+    u = calc.uscat(_dev(x.T)).cpu().numpy()
+    for s in range(2):
+        uo, go = O.plane_wave(ks[s], [1.0, 0.4])
+        res = O.solve_biem("a", centers=cen, radii=rad, k=ks[s], n_end=9, alpha=alpha[s], beta=beta[s], uin=uo, uin_grad=go)
+        ref = O.uscat(res, x)
+        assert np.max(np.abs(u[:, s] - ref) / np.abs(ref)) < 1e-10
+    # float32 in -> complex64 out, same values to single precision
+    uin32, _ = amd.plane_wave(k=_dev(1.0, torch.float32), direction=_dev([1.0, 0.0], torch.float32))
+    c32 = amd.biem(c, centers=_dev(cen, torch.float32), radii=_dev(rad, torch.float32), k=_dev(1.0, torch.float32), n_end=6, uin=uin32)
+    assert c32.density.dtype == torch.complex64
+    u32 = c32.uscat(_dev(x.T, torch.float32))
+    assert u32.dtype == torch.complex64
+    uo, _ = O.plane_wave(1.0, [1.0, 0.0])
+    ref = O.uscat(O.solve_biem("a", centers=cen, radii=rad, k=1.0, n_end=6, uin=uo), x)
+    assert np.max(np.abs(u32.cpu().numpy() - ref) / np.abs(ref)) < 1e-5

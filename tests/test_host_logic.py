@@ -97,7 +97,7 @@ def test_memory_guard_matches_reference_formulas():
 
 def test_coordinates_roundtrip_and_unsupported_tree():
     rng = np.random.default_rng(0)
-    for t in ("a", "ba", "bba"):
+    for t in ("a", "ba", "bba", "bpa", "bpbpa"):
         c = amd.create_from_branching_types(t)
         x = rng.normal(size=(c.c_ndim, 9))
         sph = c.from_cartesian(x)
@@ -106,6 +106,14 @@ def test_coordinates_roundtrip_and_unsupported_tree():
     with pytest.raises(NotImplementedError, match="planned"):
         amd.create_from_branching_types("caa")
     assert _coords.n_end_from_harm("bba", 385) == 10 and _coords.n_end_from_harm("a", 127) == 64
+    # committed bpa.svg / bpbpa.svg axis conventions
+    sph = {"r": np.asarray(2.0), 0: np.asarray(0.3), 1: np.asarray(1.1)}
+    x = amd.create_from_branching_types("bpa").to_cartesian(sph, as_array=True)
+    assert np.allclose(x, [2 * np.cos(0.3) * np.sin(1.1), 2 * np.cos(0.3) * np.cos(1.1), 2 * np.sin(0.3)])
+    sph = {"r": np.asarray(1.5), 0: np.asarray(0.2), 1: np.asarray(-0.4), 2: np.asarray(2.0)}
+    x = amd.create_from_branching_types("bpbpa").to_cartesian(sph, as_array=True)
+    c0, s0, c1, s1 = np.cos(0.2), np.sin(0.2), np.cos(-0.4), np.sin(-0.4)
+    assert np.allclose(x, [1.5 * c0 * c1 * np.sin(2.0), 1.5 * c0 * s1, 1.5 * c0 * c1 * np.cos(2.0), 1.5 * s0])
 
 
 def test_result_object_is_frozen():

@@ -39,12 +39,12 @@ def test_jascome_triplet_rows(golden_dir):
     n = 0
     for r in _rows(golden_dir, "jascome_output.csv"):
         bt, n_end = r["branching_types"], int(r["n_end"])
-        if bt not in ("a", "ba", "bba") or n_end > 6:
+        if bt not in ("a", "ba", "bba", "bpa", "bpbpa") or n_end > 6:
             continue
         u = _uscat0(bt, n_end, 1.0, O.grid_centers(0, O.tree(bt).d))
         assert abs(u - complex(r["uscat"])) < TRIPLET_TOL[n_end], (bt, n_end)
         n += 1
-    assert n == 18
+    assert n == 30
 
 
 def test_readme_doctest():
