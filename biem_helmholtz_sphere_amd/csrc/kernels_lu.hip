@@ -120,8 +120,12 @@ __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, lon
   }
   __syncthreads();
   int buf = 0;
-  for (int c = c0; c < c0 + PW; ++c) {
-    cplx* col = Ps + (size_t)c * ldp;
+  // the column loop is unrolled (cq = c - c0 is a compile-time index into the per-row register copy of the strip):
+  // per row all PW columns are LOADED FIRST (independent requests in flight), then eliminated, then stored - the earlier
+  // load/fma/store-per-element form was one dependent L2 round trip per element (no __restrict__ is possible here)
+#pragma unroll
+  for (int cq = 0; cq < PW; ++cq) {
+    const int c = c0 + cq;
     const int r0 = j + c;
     const int p = decide(buf, r0);
     if (tid == 0) ipiv[(size_t)s * n_pad + r0] = p;
@@ -136,23 +140,29 @@ __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, lon
       if (tid >= c0 && tid < c0 + PW) sU[tid - c0] = a;   // row r0 after the interchange, strip columns
     }
     __syncthreads();
-    const cplx piv = sU[c - c0];
+    const cplx piv = sU[cq];
     const bool singular = piv.x == 0.0 && piv.y == 0.0;
     if (singular && tid == 0 && info[s] == 0) info[s] = r0 + 1;
     const cplx rinv = singular ? make_double2(0.0, 0.0) : crecip(piv);
-    const bool inner = c + 1 < c0 + PW;
+    cplx u[PW];
+#pragma unroll
+    for (int q = 0; q < PW; ++q) u[q] = sU[q];
     double best = -1.0; int bi = 0x7fffffff;
     for (int i = r0 + 1 + tid; i < n_pad; i += 1024) {
-      cplx l = col[i];
-      if (!singular) { l = cmul(l, rinv); col[i] = l; }
-      for (int cc = c + 1; cc < c0 + PW; ++cc) {
-        cplx* q = Ps + (size_t)cc * ldp + i;
-        cplx v = singular ? *q : cfnma(l, sU[cc - c0], *q);
-        *q = v;
-        if (cc == c + 1) { double a = fabs(v.x) + fabs(v.y); if (a > best) { best = a; bi = i; } }
+      cplx v[PW];
+#pragma unroll
+      for (int q = cq; q < PW; ++q) v[q] = Ps[(size_t)(c0 + q) * ldp + i];
+      if (!singular) {
+        const cplx l = cmul(v[cq], rinv);
+        v[cq] = l;
+#pragma unroll
+        for (int q = cq + 1; q < PW; ++q) v[q] = cfnma(l, u[q], v[q]);
       }
+#pragma unroll
+      for (int q = cq; q < PW; ++q) Ps[(size_t)(c0 + q) * ldp + i] = v[q];
+      if (cq + 1 < PW) { double a = fabs(v[cq + 1 < PW ? cq + 1 : cq].x) + fabs(v[cq + 1 < PW ? cq + 1 : cq].y); if (a > best) { best = a; bi = i; } }
     }
-    if (inner) { publish(best, bi, buf ^ 1); buf ^= 1; }
+    if (cq + 1 < PW) { publish(best, bi, buf ^ 1); buf ^= 1; }
     __syncthreads();
   }
   const int nright = NB - (c0 + PW);
@@ -193,12 +203,17 @@ __global__ void __launch_bounds__(256) k_panel_update(cplx* __restrict__ Pw, lon
   cplx l[PW];
 #pragma unroll
   for (int q = 0; q < PW; ++q) l[q] = Ps[(size_t)(c0 + q) * ldp + i];
-  for (int t = 0; t < nright; ++t) {
-    cplx* q_ = Ps + (size_t)(c0 + PW + t) * ldp + i;
-    cplx v = *q_;
+  // nright is a multiple of PW: 8 independent loads, 64 complex FMAs, 8 stores per group
+  for (int t0 = 0; t0 < nright; t0 += PW) {
+    cplx v[PW];
 #pragma unroll
-    for (int q = 0; q < PW; ++q) v = cfnma(l[q], sUr[q][t], v);
-    *q_ = v;
+    for (int t = 0; t < PW; ++t) v[t] = Ps[(size_t)(c0 + PW + t0 + t) * ldp + i];
+#pragma unroll
+    for (int t = 0; t < PW; ++t)
+#pragma unroll
+      for (int q = 0; q < PW; ++q) v[t] = cfnma(l[q], sUr[q][t0 + t], v[t]);
+#pragma unroll
+    for (int t = 0; t < PW; ++t) Ps[(size_t)(c0 + PW + t0 + t) * ldp + i] = v[t];
   }
 }
 
