@@ -243,155 +243,27 @@ __global__ void __launch_bounds__(256) k_swap(cplx* __restrict__ A, long long ld
 }
 
 // ---------------------------------------------------------------------------------------------
-// U12 = L11^{-1} A12 on a [NB x TC] column tile held in LDS; L11 (unit lower) is read from the panel workspace.
-// ---------------------------------------------------------------------------------------------
-constexpr int TC = 32;
-__global__ void __launch_bounds__(256) k_trsm(cplx* __restrict__ A, long long lda, long long sys_stride, const cplx* __restrict__ Pw,
-                                               long long ldp, long long p_stride, int n_cols, int j) {
-  __shared__ cplx tile[NB][TC + 1];
-  const int s = blockIdx.y, c0 = j + NB + blockIdx.x * TC;
-  cplx* As = A + (size_t)s * sys_stride;
-  const cplx* Ps = Pw + (size_t)s * p_stride;
-  const int n = threadIdx.x % TC, g = threadIdx.x / TC;   // 8 row groups
-  const bool ok = c0 + n < n_cols;
-  for (int r = g; r < NB; r += 8) tile[r][n] = ok ? As[(size_t)(j + r) * lda + c0 + n] : make_double2(0.0, 0.0);
-  __syncthreads();
-  for (int r = 0; r < NB - 1; ++r) {
-    cplx u = tile[r][n];
-    for (int i = r + 1 + g; i < NB; i += 8) {
-      cplx l = Ps[(size_t)r * ldp + j + i];
-      tile[i][n] = cfnma(l, u, tile[i][n]);
-    }
-    __syncthreads();
-  }
-  if (ok) for (int r = g; r < NB; r += 8) As[(size_t)(j + r) * lda + c0 + n] = tile[r][n];
-}
-
-// ---------------------------------------------------------------------------------------------
-// trailing update  C[i][n] -= sum_c L21[i][c] U12[c][n]   --  zgemm on v_mfma_f64_16x16x4_f64.
-//   A operand = L21 from the column-major panel workspace P[c][i]  -> LDS sA[k][i]   (no transpose)
-//   B operand = U12 rows of M, row-major [c][n]                      -> LDS sB[k][n]   (no transpose)
-//   f64 MFMA fragments: lane l holds A[i = l&15][k = l>>4], B[k = l>>4][n = l&15]; C/D: col = l&15, row = (l>>4) + 4*reg.
-//   complex product = 4 real MFMAs: Cr += Ar*Br; Cr += (-Ai)*Bi; Ci += Ar*Bi; Ci += Ai*Br.
-// Workgroup tile 128 x 128, 8 waves as 4(M) x 2(N), wave tile 32 x 64 = 2 x 4 MFMA tiles (16 accumulator tiles of 4 f64:
-// 128 VGPRs), K staged in chunks of 8 through double-buffered LDS (64 KiB), one barrier per chunk.
-// LDS reads are ds_read_b128 of 16 consecutive complex per k-row: conflict-free (MI355X_MICROARCH.md, LDS table).
-// ---------------------------------------------------------------------------------------------
-constexpr int BM = 128, BN = 128, KC = 8;
-
-__global__ void __launch_bounds__(512) k_gemm(cplx* __restrict__ A, long long lda, long long sys_stride, const cplx* __restrict__ Pw,
-                                               long long ldp, long long p_stride, int n_pad, int n_cols, int j) {
-  __shared__ cplx sA[2][KC][BM];
-  __shared__ cplx sB[2][KC][BN];
-  const int s = blockIdx.z;
-  const int row0 = j + NB + blockIdx.y * BM;
-  const int col0 = j + NB + blockIdx.x * BN;
-  cplx* As = A + (size_t)s * sys_stride;
-  const cplx* Ps = Pw + (size_t)s * p_stride;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l15 = lane & 15, l4 = lane >> 4;
-
-  v4d accR[2][4], accI[2][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) { accR[a][b] = (v4d){0, 0, 0, 0}; accI[a][b] = (v4d){0, 0, 0, 0}; }
-
-  // staging map: element id = tid + 512 r (r = 0, 1): k-row = id >> 7, position = id & 127
-  const int sk0 = tid >> 7, si = tid & 127;
-  const bool rowok = row0 + si < n_pad, colok = col0 + si < n_cols;
-  cplx ra[2], rb[2];
-  const cplx zero = make_double2(0.0, 0.0);
-  auto gload = [&](int kc) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      int kk = kc + sk0 + 4 * r;
-      ra[r] = rowok ? Ps[(size_t)kk * ldp + row0 + si] : zero;
-      rb[r] = colok ? As[(size_t)(j + kk) * lda + col0 + si] : zero;
-    }
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      sA[buf][sk0 + 4 * r][si] = ra[r];
-      sB[buf][sk0 + 4 * r][si] = rb[r];
-    }
-  };
-  gload(0);
-  sstore(0);
-  __syncthreads();
-  for (int kc = 0; kc < NB; kc += KC) {
-    const int buf = (kc / KC) & 1;
-    const bool more = kc + KC < NB;
-    if (more) gload(kc + KC);
-#pragma unroll
-    for (int k4 = 0; k4 < KC / 4; ++k4) {
-      const int kk = k4 * 4 + l4;
-      cplx a[2], b[4];
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) a[tm] = sA[buf][kk][wm * 32 + tm * 16 + l15];
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) b[tn] = sB[buf][kk][wn * 64 + tn * 16 + l15];
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-        const double nai = -a[tm].y;
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-          accR[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm].x, b[tn].x, accR[tm][tn], 0, 0, 0);
-          accI[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm].x, b[tn].y, accI[tm][tn], 0, 0, 0);
-          accR[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(nai, b[tn].y, accR[tm][tn], 0, 0, 0);
-          accI[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm].y, b[tn].x, accI[tm][tn], 0, 0, 0);
-        }
-      }
-    }
-    if (more) sstore(buf ^ 1);
-    __syncthreads();
-  }
-  // epilogue: C -= acc
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-      const int col = col0 + wn * 64 + tn * 16 + l15;
-      if (col >= n_cols) continue;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = row0 + wm * 32 + tm * 16 + l4 + 4 * r;
-        if (row < n_pad) {
-          cplx* q = As + (size_t)row * lda + col;
-          cplx c = *q;
-          c.x -= accR[tm][tn][r];
-          c.y -= accI[tm][tn][r];
-          *q = c;
-        }
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// trailing update (product kernel) -- persistent zgemm on v_mfma_f64_4x4x4_4b_f64.
+// trailing update -- persistent zgemm on v_mfma_f64_4x4x4_4b_f64 (kernel below: k_gemm3m_pipe).
 //
-// MFMA form.  Measured on MI355X (tools/mfma_probe.hip, profiles/r01_mfma_f64_probe.txt): the 16x16x4 f64 MFMA
+// MFMA form.  Measured on MI355X (tools/mfma_probe*.hip, profiles/r01_mfma_f64_*probe*.txt): the 16x16x4 f64 MFMA
 // saturates at ~47-49 TFLOP/s (one per ~100 cycles per SIMD) at any occupancy, the 4-block 4x4x4 form issues every
-// ~17 cycles = 65-70 TFLOP/s.  The 4-block form multiplies A_blk (4x4) by B_blk (4x4) for blk = 0..3 (lane l:
-// i|j = l&3, blk = (l>>2)&3, k = l>>4; D: j = l&3, blk, i = l>>4; CBSZ/ABID are not honoured for f64:
-// profiles/r01_mfma_f64_4x4x4_layout.txt), so a 16x16 tile is built from 4 instructions whose A fragment holds the
-// SAME 4-row block in all four slots (an LDS broadcast read): accumulator g = rows 4g..4g+3 x 16 columns, i.e.
+// 16.3 cycles = 75-78 TFLOP/s with >= 48 independent accumulators.  The 4-block form multiplies A_blk (4x4) by B_blk (4x4)
+// for blk = 0..3 (lane l: i|j = l&3, blk = (l>>2)&3, k = l>>4; D: j = l&3, blk, i = l>>4; CBSZ/ABID are not honoured
+// for f64: profiles/r01_mfma_f64_4x4x4_layout.txt), so a 16x16 tile is built from 4 instructions whose A fragment holds
+// the SAME 4-row block in all four slots (an LDS broadcast read): accumulator g = rows 4g..4g+3 x 16 columns, i.e.
 // register g of the 16x16x4 result layout.  The f64 NEG bits (blgp bit 0 negates A) give acc = C - A*B directly.
 //
 // Memory schedule.  With K = NB the update is only 16 flop per byte of C traffic; a read-modify-write epilogue leaves
 // every wave ~60 % of its cycles in s_waitcnt (profiles/r01_gemm_pmc.txt) because all workgroups hit HBM together and
-// the MFMAs then idle.  Here each workgroup is persistent and streams: the C tile is loaded in slices during the
-// K-chunks (the accumulator of sub-tile c receives its C values in chunk c), the final stores stay in flight while
-// the next tile starts, and the first A/B chunk of the next tile is fetched during the last chunk of the current one.
+// the MFMAs then idle.  Each workgroup is persistent and streams: the C tile is loaded in slices during the K-chunks,
+// the final stores stay in flight while the next tile starts, and the operand stream runs ahead across tile boundaries.
 //
 // Tile order.  Tiles are numbered system-major, then bands of 8 tile-rows, then column-major inside a band, so 64
-// consecutive tiles form an 8 x 8 block sharing 8 A- and 8 B-panels.  Workgroup w takes tiles 64 (8 it + w%8) + w/8:
-// the 64 workgroups that share w%8 (one XCD under the observed round-robin placement; speed only) sweep one block.
+// consecutive tiles form an 8 x 8 block sharing 8 A- and 8 B-panels.  The workgroups that share blockIdx % 8 (one XCD
+// under the observed round-robin placement; speed only) sweep one block together.
+// (Superseded variants - 16x16x4 MFMA with RMW epilogue, 2-stage 4M and 3M kernels - are described with their numbers
+// in DESIGN.md section 5; their sources are in the git history.)
 // ---------------------------------------------------------------------------------------------
-constexpr int BM2 = 64, BN2 = 128;
 
 struct TileGrid {
   int ty_n, tx_n, per_sys, full_bands, ntiles;
@@ -412,323 +284,8 @@ __device__ inline void tile_decode(const TileGrid& tg, int t, int& s, int& ty, i
   }
 }
 
-template <int KD>
-__global__ void __launch_bounds__(256, 2) k_gemm_stream(cplx* __restrict__ A, long long lda, long long sys_stride,
-                                                         const cplx* __restrict__ Pw, long long ldp, long long p_stride,
-                                                         TileGrid tg) {
-  const int n_pad = tg.row_end, n_cols = tg.col_end;
-  constexpr int NCH = KD / KC;               // K-chunks per tile (8 or 16): even, so LDS buffer parity carries over tiles
-  constexpr int CSTEP = NCH / 8;             // a C slice is loaded every CSTEP chunks
-  __shared__ cplx sA[2][KC][BM2];
-  __shared__ cplx sB[2][KC][BN2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l3 = lane & 3, l15 = lane & 15, l4 = lane >> 4;
-  // tile sequence of this workgroup: blocks bi = w%8, w%8 + 8, ..; inside a block slots w/8, w/8 + nblk, .. (< 64)
-  const int w = blockIdx.x, slot0 = w >> 3, nblk = gridDim.x >> 3;
-  int bi = w & 7, sl = slot0 - nblk;
-  auto next_tile = [&]() -> int {
-    for (;;) {
-      sl += nblk;
-      if (sl >= 64) { sl = slot0; bi += 8; }
-      if (64 * bi >= tg.ntiles) return -1;
-      int t = 64 * bi + sl;
-      if (t < tg.ntiles) return t;
-    }
-  };
-  int t = next_tile();
-  if (t < 0) return;
-
-  // staging by LDS-DMA (global_load_lds_dwordx4): one wave-instruction = one contiguous 1 KiB k-row segment, so the
-  // LDS image [k][i] needs no VGPR round trip.  Out-of-range lanes are masked: their LDS slots keep stale values,
-  // which only reach accumulator rows/columns that are never stored.
-  const int ak = tid >> 6, ai = tid & 63;          // A: k-rows ak + 4 r, element ai
-  const int bk = tid >> 7, bq = tid & 127;         // B: k-rows bk + 2 r, element bq (wave-uniform segment (wave & 1) * 64)
-  const cplx zero = make_double2(0.0, 0.0);
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-
-  int cs, cty, ctx;
-  tile_decode(tg, t, cs, cty, ctx);
-  auto stage = [&](int s_, int ty_, int tx_, int kc, int buf) {
-    const cplx* Ps = Pw + (size_t)s_ * p_stride;
-    const cplx* As = A + (size_t)s_ * sys_stride;
-    const int r0 = tg.row_begin + ty_ * BM2, c0 = tg.col_begin + tx_ * BN2;
-    if (r0 + ai < n_pad) {
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ps + (size_t)(kc + ak + 4 * r) * ldp + r0 + ai),
-                                         (lds_ptr_t)(&sA[buf][ak + 4 * r][0]), 16, 0, 0);
-    }
-    if (c0 + bq < n_cols) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(As + (size_t)(tg.brow + kc + bk + 2 * r) * lda + c0 + bq),
-                                         (lds_ptr_t)(&sB[buf][bk + 2 * r][(wave & 1) * 64]), 16, 0, 0);
-    }
-  };
-
-  double accR[2][4][4], accI[2][4][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) { accR[a][b][g] = 0.0; accI[a][b][g] = 0.0; }
-
-  stage(cs, cty, ctx, 0, 0);
-  __syncthreads();
-
-  for (;;) {
-    cplx* Cs = A + (size_t)cs * sys_stride;
-    const int row0 = tg.row_begin + cty * BM2, col0 = tg.col_begin + ctx * BN2;
-    int tn = -1, ns = 0, nty = 0, ntx = 0;
-#pragma unroll 1
-    for (int c = 0; c < NCH; ++c) {
-      const int buf = c & 1;
-      // next chunk (or the first chunk of the next tile) lands in the other buffer while this one is multiplied;
-      // the barrier at the end of the chunk waits for it (vmcnt(0) + s_barrier)
-      if (c + 1 < NCH) {
-        stage(cs, cty, ctx, (c + 1) * KC, buf ^ 1);
-      } else {
-        tn = next_tile();
-        if (tn >= 0) { tile_decode(tg, tn, ns, nty, ntx); stage(ns, nty, ntx, 0, buf ^ 1); }
-      }
-      // C slice of sub-tile number c / CSTEP = (tm, tn): issued now, consumed after this chunk's MFMAs
-      cplx cl[4];
-      const bool cslice = (c % CSTEP) == 0;
-      const int cq = c / CSTEP;
-      if (cslice) {
-        const int col = col0 + wn * 64 + (cq & 3) * 16 + l15;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = row0 + wm * 32 + (cq >> 2) * 16 + 4 * g + l4;
-          cl[g] = (col < n_cols && row < n_pad) ? Cs[(size_t)row * lda + col] : zero;
-        }
-      }
-#pragma unroll
-      for (int k4 = 0; k4 < KC / 4; ++k4) {
-        const int kk = k4 * 4 + l4;
-        cplx b[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) b[q] = sB[buf][kk][wn * 64 + q * 16 + l15];
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-          cplx a[4];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) a[g] = sA[buf][kk][wm * 32 + tm * 16 + 4 * g + l3];
-          // acc = C - A*B:  Re: -(ArBr) + AiBi,  Im: -(ArBi) - (AiBr); dependent MFMAs are 16 instructions apart
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) accR[tm][q][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[g].x, b[q].x, accR[tm][q][g], 0, 0, 1);
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) accI[tm][q][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[g].x, b[q].y, accI[tm][q][g], 0, 0, 1);
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) accR[tm][q][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[g].y, b[q].y, accR[tm][q][g], 0, 0, 0);
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) accI[tm][q][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[g].y, b[q].x, accI[tm][q][g], 0, 0, 1);
-        }
-      }
-      if (cslice) {
-#define BIEM_CADD(TM, TN) _Pragma("unroll") for (int g = 0; g < 4; ++g) { accR[TM][TN][g] += cl[g].x; accI[TM][TN][g] += cl[g].y; }
-        switch (cq) {   // wave-uniform: the accumulator index has to be a compile-time constant
-          case 0: BIEM_CADD(0, 0) break;
-          case 1: BIEM_CADD(0, 1) break;
-          case 2: BIEM_CADD(0, 2) break;
-          case 3: BIEM_CADD(0, 3) break;
-          case 4: BIEM_CADD(1, 0) break;
-          case 5: BIEM_CADD(1, 1) break;
-          case 6: BIEM_CADD(1, 2) break;
-          default: BIEM_CADD(1, 3) break;
-        }
-#undef BIEM_CADD
-      }
-      __syncthreads();
-    }
-    // results: plain stores, left in flight while the next tile starts
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int col = col0 + wn * 64 + q * 16 + l15;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = row0 + wm * 32 + tm * 16 + 4 * g + l4;
-          if (col < n_cols && row < n_pad) Cs[(size_t)row * lda + col] = make_double2(accR[tm][q][g], accI[tm][q][g]);
-          accR[tm][q][g] = 0.0; accI[tm][q][g] = 0.0;
-        }
-      }
-    }
-    if (tn < 0) break;
-    cs = ns; cty = nty; ctx = ntx;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// trailing update, 3M form (default): the same streaming schedule with 3 real products per complex product
-//   T1 = Ar Br,  T2 = Ai Bi,  T3 = (Ar + Ai)(Br + Bi);   Re(AB) = T1 - T2,  Im(AB) = T3 - T1 - T2     (as in BLAS zgemm3m)
-// i.e. 25 % fewer MFMAs for the same 8 flop per complex multiply-add of algorithmic work.  Three accumulator sets per
-// sub-tile: N1 = Cr - T1,  P2 = T2,  N3 = (Cr + Ci) - T3;  result Cr' = N1 + P2,  Ci' = N3 - N1 + P2.
-// The rounding is norm-wise (|Ar|+|Ai|)(|Br|+|Bi|) eps instead of component-wise - far inside the 1e-10 budget of the path.
-// Workgroup = 256 threads (2 x 2 waves, wave tile 32 x 32), tile 64 x 64, 32 KiB LDS, <= 168 VGPRs: three per CU.
-// ---------------------------------------------------------------------------------------------
-constexpr int BM3 = 64, BN3 = 64;
-
-template <int KD>
-__global__ void __launch_bounds__(256, 3) k_gemm3m_stream(cplx* __restrict__ A, long long lda, long long sys_stride,
-                                                           const cplx* __restrict__ Pw, long long ldp, long long p_stride,
-                                                           TileGrid tg) {
-  const int n_pad = tg.row_end, n_cols = tg.col_end;
-  constexpr int NCH = KD / KC;               // 8 or 16 K-chunks per tile
-  constexpr int UPC = 16 / NCH;              // C units (one complex per lane) fetched per chunk: 2 or 1
-  __shared__ cplx sA[2][KC][BM3];
-  __shared__ cplx sB[2][KC][BN3];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l3 = lane & 3, l15 = lane & 15, l4 = lane >> 4;
-  // tile sequence: label x = w % 8 owns the 64-tile blocks x, x + 8, ..; its workgroups r = w / 8 take positions
-  // r, r + nblk, .. of the label's concatenated block sequence
-  const int w = blockIdx.x, nblk = gridDim.x >> 3, xl = w & 7;
-  int q = (w >> 3) - nblk;
-  auto next_tile = [&]() -> int {
-    for (;;) {
-      q += nblk;
-      int base = 64 * ((q >> 6) * 8 + xl);
-      if (base >= tg.ntiles) return -1;
-      int t = base + (q & 63);
-      if (t < tg.ntiles) return t;
-    }
-  };
-  int t = next_tile();
-  if (t < 0) return;
-
-  const cplx zero = make_double2(0.0, 0.0);
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-  int cs, cty, ctx;
-  tile_decode(tg, t, cs, cty, ctx);
-  // LDS-DMA staging: wave `wave` brings k-rows wave and wave + 4 of both operands (one contiguous 1 KiB row each)
-  auto stage = [&](int s_, int ty_, int tx_, int kc, int buf) {
-    const cplx* Ps = Pw + (size_t)s_ * p_stride;
-    const cplx* As = A + (size_t)s_ * sys_stride;
-    const int r0 = tg.row_begin + ty_ * BM3, c0 = tg.col_begin + tx_ * BN3;
-    if (r0 + lane < n_pad) {
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ps + (size_t)(kc + wave + 4 * r) * ldp + r0 + lane),
-                                         (lds_ptr_t)(&sA[buf][wave + 4 * r][0]), 16, 0, 0);
-    }
-    if (c0 + lane < n_cols) {
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(As + (size_t)(tg.brow + kc + wave + 4 * r) * lda + c0 + lane),
-                                         (lds_ptr_t)(&sB[buf][wave + 4 * r][0]), 16, 0, 0);
-    }
-  };
-
-  double N1[2][2][4], P2[2][2][4], N3[2][2][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) { N1[a][b][g] = 0.0; P2[a][b][g] = 0.0; N3[a][b][g] = 0.0; }
-
-  stage(cs, cty, ctx, 0, 0);
-  __syncthreads();
-
-  for (;;) {
-    cplx* Cs = A + (size_t)cs * sys_stride;
-    const int row0 = tg.row_begin + cty * BM3, col0 = tg.col_begin + ctx * BN3;
-    int tn_ = -1, ns = 0, nty = 0, ntx = 0;
-#pragma unroll 1
-    for (int c = 0; c < NCH; ++c) {
-      const int buf = c & 1;
-      if (c + 1 < NCH) {
-        stage(cs, cty, ctx, (c + 1) * KC, buf ^ 1);
-      } else {
-        tn_ = next_tile();
-        if (tn_ >= 0) { tile_decode(tg, tn_, ns, nty, ntx); stage(ns, nty, ntx, 0, buf ^ 1); }
-      }
-      // C units u = c*UPC + i  ->  (tm, tn, g) = (u >> 3, (u >> 2) & 1, u & 3): issued now, consumed after the MFMAs
-      cplx cl[UPC];
-#pragma unroll
-      for (int i = 0; i < UPC; ++i) {
-        const int u = c * UPC + i;
-        const int row = row0 + wm * 32 + (u >> 3) * 16 + 4 * (u & 3) + l4;
-        const int col = col0 + wn * 32 + ((u >> 2) & 1) * 16 + l15;
-        cl[i] = (col < n_cols && row < n_pad) ? Cs[(size_t)row * lda + col] : zero;
-      }
-#pragma unroll
-      for (int k4 = 0; k4 < KC / 4; ++k4) {
-        const int kk = k4 * 4 + l4;
-        cplx b[2];
-        double bs[2];
-#pragma unroll
-        for (int n = 0; n < 2; ++n) { b[n] = sB[buf][kk][wn * 32 + n * 16 + l15]; bs[n] = b[n].x + b[n].y; }
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-          cplx a[4];
-          double as[4];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) { a[g] = sA[buf][kk][wm * 32 + tm * 16 + 4 * g + l3]; as[g] = a[g].x + a[g].y; }
-#pragma unroll
-          for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) N1[tm][n][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[g].x, b[n].x, N1[tm][n][g], 0, 0, 1);
-#pragma unroll
-          for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) P2[tm][n][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[g].y, b[n].y, P2[tm][n][g], 0, 0, 0);
-#pragma unroll
-          for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) N3[tm][n][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(as[g], bs[n], N3[tm][n][g], 0, 0, 1);
-        }
-      }
-#define BIEM_CADD3(U, V) { N1[(U) >> 3][((U) >> 2) & 1][(U) & 3] += (V).x; N3[(U) >> 3][((U) >> 2) & 1][(U) & 3] += (V).x + (V).y; }
-#pragma unroll
-      for (int i = 0; i < UPC; ++i) {
-        switch (c * UPC + i) {   // wave-uniform; accumulator indices must be compile-time constants
-          case 0: BIEM_CADD3(0, cl[i]) break;   case 1: BIEM_CADD3(1, cl[i]) break;
-          case 2: BIEM_CADD3(2, cl[i]) break;   case 3: BIEM_CADD3(3, cl[i]) break;
-          case 4: BIEM_CADD3(4, cl[i]) break;   case 5: BIEM_CADD3(5, cl[i]) break;
-          case 6: BIEM_CADD3(6, cl[i]) break;   case 7: BIEM_CADD3(7, cl[i]) break;
-          case 8: BIEM_CADD3(8, cl[i]) break;   case 9: BIEM_CADD3(9, cl[i]) break;
-          case 10: BIEM_CADD3(10, cl[i]) break; case 11: BIEM_CADD3(11, cl[i]) break;
-          case 12: BIEM_CADD3(12, cl[i]) break; case 13: BIEM_CADD3(13, cl[i]) break;
-          case 14: BIEM_CADD3(14, cl[i]) break; default: BIEM_CADD3(15, cl[i]) break;
-        }
-      }
-#undef BIEM_CADD3
-      __syncthreads();
-    }
-    // Cr' = N1 + P2, Ci' = N3 - N1 + P2; plain stores stay in flight while the next tile starts
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-#pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const int col = col0 + wn * 32 + n * 16 + l15;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = row0 + wm * 32 + tm * 16 + 4 * g + l4;
-          if (col < n_cols && row < n_pad)
-            Cs[(size_t)row * lda + col] = make_double2(N1[tm][n][g] + P2[tm][n][g], N3[tm][n][g] - N1[tm][n][g] + P2[tm][n][g]);
-          N1[tm][n][g] = 0.0; P2[tm][n][g] = 0.0; N3[tm][n][g] = 0.0;
-        }
-      }
-    }
-    if (tn_ < 0) break;
-    cs = ns; cty = nty; ctx = ntx;
-  }
-}
+constexpr int BM3 = 64, BN3 = 64;   // workgroup tile of the trailing update
+constexpr int KC = 8;               // K rows per LDS stage (chunk)
 
 // ---------------------------------------------------------------------------------------------
 // trailing update, 3M form with a 3-stage LDS-DMA ring (product kernel).
@@ -1043,33 +600,18 @@ static void launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, l
                                int prof_class = PK_GEMM, double prof_work = -1.0) {
   const int rrows = row_end - row_begin, rcols = col_end - col_begin;
   if (rrows <= 0 || rcols <= 0) return;
-  static const bool use4m = getenv("BIEM_GEMM_4M") != nullptr;   // A/B switch for the design notes; 3M is the product
-  const int bm = use4m ? BM2 : BM3, bn = use4m ? BN2 : BN3;
   TileGrid tg;
-  tg.ty_n = (rrows + bm - 1) / bm; tg.tx_n = (rcols + bn - 1) / bn;
+  tg.ty_n = (rrows + BM3 - 1) / BM3; tg.tx_n = (rcols + BN3 - 1) / BN3;
   tg.per_sys = tg.ty_n * tg.tx_n; tg.full_bands = tg.ty_n / 8; tg.ntiles = tg.per_sys * nb;
   tg.row_begin = row_begin; tg.row_end = row_end; tg.col_begin = col_begin; tg.col_end = col_end; tg.brow = brow;
-  static const bool use2stage = getenv("BIEM_GEMM_2STAGE") != nullptr;
-  const int cap = (use4m || !use2stage) ? 512 : 768;   // persistent grid: workgroups per CU x 256
+  const int cap = 512;                         // persistent grid: 2 workgroups per CU
   int want = (tg.ntiles + 7) / 8 * 8;          // one workgroup per tile up to the cap, multiple of 8
   int grid = want < cap ? want : cap;
   ProfScope ps(prof_class, st, prof_work >= 0.0 ? prof_work : 8.0 * (double)nb * rrows * (double)rcols * kd);
-  if (use4m) {
-    if (kd == 64)
-      hipLaunchKernelGGL(k_gemm_stream<64>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
-    else
-      hipLaunchKernelGGL(k_gemm_stream<128>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
-  } else if (use2stage) {
-    if (kd == 64)
-      hipLaunchKernelGGL(k_gemm3m_stream<64>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
-    else
-      hipLaunchKernelGGL(k_gemm3m_stream<128>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
-  } else {
-    if (kd == 64)
-      hipLaunchKernelGGL(k_gemm3m_pipe<64>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
-    else
-      hipLaunchKernelGGL(k_gemm3m_pipe<128>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
-  }
+  if (kd == 64)
+    hipLaunchKernelGGL(k_gemm3m_pipe<64>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
+  else
+    hipLaunchKernelGGL(k_gemm3m_pipe<128>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
 }
 
 // W = I - L11^{-1} for the unit-lower 64 x 64 diagonal block of a panel, stored [k][i] (the MFMA A-operand order), so that
@@ -1167,7 +709,6 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
   cplx* Pw = (cplx*)d_work;
   const long long ldp = ldp_of(n_pad), p_stride = 2LL * NB * ldp;
   const int n_cols = n_pad + nrhs;
-  static const int gemm_variant = getenv("BIEM_GEMM_V1") ? 1 : 2;   // A/B switch for the design notes; v2 is the product
   hipLaunchKernelGGL(k_zero_int, dim3((nb + 63) / 64), dim3(64), 0, st, d_info, nb);
   static bool inv_attr = false;
   if (!inv_attr) {
@@ -1204,12 +745,6 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     const int rcols = n_cols - (j + NB);
     if (rcols <= 0) return;
     const double work = 4.0 * (double)nb * NB * NB * rcols;
-    if (gemm_variant == 1) {
-      ProfScope ps(PK_TRSM, st, work);
-      hipLaunchKernelGGL(k_trsm, dim3((rcols + TC - 1) / TC, nb), dim3(256), 0, st, A, lda, sys_stride, Pw + (size_t)pc * ldp, ldp,
-                         p_stride, n_cols, j);
-      return;
-    }
     {
       ProfScope ps(PK_TRSM, st, 0.0);
       hipLaunchKernelGGL(k_inv_l11, dim3(nb), dim3(64), 2 * NB * NB * sizeof(cplx), st, Pw + (size_t)pc * ldp, ldp, p_stride, j, Winv);
@@ -1218,18 +753,7 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     launch_gemm_stream(st, nb, A, lda, sys_stride, Winv - j, NB, (long long)NB * NB, j, j + NB, j + NB, n_cols, j, NB, PK_TRSM, work);
   };
 
-  if (gemm_variant == 1) {
-    // v1 reference schedule: K = 64 steps, 16x16x4 MFMA with a read-modify-write epilogue
-    for (int j = 0; j < n_pad; j += NB) {
-      panel(j, 0); swap_right(j); trsm(j, 0);
-      const int rcols = n_cols - (j + NB), rrows = n_pad - (j + NB);
-      if (rcols > 0 && rrows > 0) {
-        ProfScope ps(PK_GEMM, st, 8.0 * (double)nb * rrows * (double)rcols * NB);
-        hipLaunchKernelGGL(k_gemm, dim3((rcols + BN - 1) / BN, (rrows + BM - 1) / BM, nb), dim3(512), 0, st, A, lda, sys_stride, Pw,
-                           ldp, p_stride, n_pad, n_cols, j);
-      }
-    }
-  } else {
+  {
     // two-level schedule, block = two 64-column panels a (at J) and b (at J + 64):
     //   a: factor, interchanges, U row block; its K = 64 update goes only to the 64 columns panel b consists of
     //   b: factor, interchanges (also on a's stored multipliers); only now - with the rows in their final order - a's
