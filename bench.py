@@ -84,14 +84,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; BIEM_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box only) folds the ranks onto the visible devices
+    share = os.environ.get("BIEM_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if share:
+            dist.init_process_group(backend="gloo")           # RCCL refuses two ranks on one device
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
     import biem_helmholtz_sphere_amd as amd
     from biem_helmholtz_sphere_amd import _lib as L
@@ -127,7 +133,7 @@ def main():
     launches = (C.c_longlong * 9)()
     L.check(lib.biem_profile_end(ms, work, launches))
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

@@ -66,10 +66,17 @@ def load() -> C.CDLL:
         if _lib is not None:
             return _lib
         if not os.path.exists(LIB_PATH):
-            raise BiemLibraryError(
-                f"{LIB_PATH} is missing. Build it with `python -m biem_helmholtz_sphere_amd._build` "
-                "(hipcc --offload-arch=gfx950). This package has no CPU fallback."
-            )
+            # not a fallback: the same HIP library, compiled now if the toolchain is present
+            try:
+                from . import _build
+
+                _build.build(force=True)
+            except Exception as e:  # noqa: BLE001
+                raise BiemLibraryError(
+                    f"{LIB_PATH} is missing and could not be built ({e}). Build it with "
+                    "`python -m biem_helmholtz_sphere_amd._build` (hipcc --offload-arch=gfx950). "
+                    "This package has no CPU fallback."
+                ) from e
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
