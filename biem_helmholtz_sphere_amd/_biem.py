@@ -204,7 +204,7 @@ class _Plan:
     def quad_shape(self) -> Tuple[int, ...]:
         """Tensor-product shape of the rule, one axis per spherical node (the reference's ...(f) axes)."""
         n = self.n_end
-        return {"a": (2 * n,), "ba": (n, 2 * n), "bba": (n, n, 2 * n)}[self.tree]
+        return {"a": (2 * n,), "ba": (n, 2 * n), "bba": (n, n, 2 * n), "caa": (n, 2 * n, 2 * n)}[self.tree]
 
 
 _PLANS: dict = {}

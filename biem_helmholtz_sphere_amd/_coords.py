@@ -9,6 +9,7 @@ committed ``a.svg / ba.svg / bba.svg``:
     ba  : x0 = r cos t0,  x1 = r sin t0 cos t1,  x2 = r sin t0 sin t1
     bba : x0 = r cos t0,  x1 = r sin t0 cos t1,  x2 = r sin t0 sin t1 cos t2,  x3 = r sin t0 sin t1 sin t2
     bpa, bpbpa : primed polar nodes measure the angle from the equator (t in [-pi/2, pi/2]); see CANONICAL below
+    caa : x0 = r cos t0 cos t1,  x1 = r cos t0 sin t1,  x2 = r sin t0 cos t2,  x3 = r sin t0 sin t2   (t0 in [0, pi/2])
 
 Works on torch tensors and NumPy arrays alike (only elementwise maths is used).
 """
@@ -17,8 +18,8 @@ from __future__ import annotations
 import math
 from typing import Any, Mapping
 
-SUPPORTED = {"a": 2, "ba": 3, "bba": 4, "bpa": 3, "bpbpa": 4}
-NEXT = ("caa",)  # not built yet
+SUPPORTED = {"a": 2, "ba": 3, "bba": 4, "bpa": 3, "bpbpa": 4, "caa": 4}
+NEXT = ()
 # Trees with primed (b') nodes, in the axis convention of the reference's committed bpa.svg / bpbpa.svg (its jascome driver
 # relabels node 0 <-> d-1 first, cli.py:65-69): they are ba / bba in permuted Cartesian axes, canonical y_i = x_{perm[i]}:
 #   bpa   : x2 = r sin t0, x1 = r cos t0 cos t1, x0 = r cos t0 sin t1                      -> (y0, y1, y2) = (x2, x1, x0)
@@ -78,6 +79,15 @@ class SphericalCoordinates:
         """{"r": r (optional, default 1), 0: theta0, 1: theta1, ...} -> cartesian (stacked on axis 0 if as_array)."""
         th = [spherical[i] for i in range(self.s_ndim)]
         xp = _xp(th[0])
+        if self.branching_types_expression_str == "caa":
+            c0, s0 = xp.cos(th[0]), xp.sin(th[0])
+            comps = [c0 * xp.cos(th[1]), c0 * xp.sin(th[1]), s0 * xp.cos(th[2]), s0 * xp.sin(th[2])]
+            if "r" in spherical:
+                comps = [spherical["r"] * v for v in comps]
+            if as_array:
+                comps = xp.broadcast_arrays(*comps) if xp.__name__ == "numpy" else xp.broadcast_tensors(*comps)
+                return xp.stack(list(comps), 0)
+            return {i: v for i, v in enumerate(comps)}
         if self.branching_types_expression_str in CANONICAL:
             # b' angle t (from the equator) = pi/2 - colatitude of the canonical tree, for every polar node
             base, perm = CANONICAL[self.branching_types_expression_str]
@@ -112,6 +122,10 @@ class SphericalCoordinates:
         """cartesian x[d, ...] (array or mapping 0..d-1) -> {"r": r, 0: theta0, ...}; polar angles in [0, pi], last in (-pi, pi]."""
         xs = [x[i] for i in range(self.c_ndim)]
         xp = _xp(xs[0])
+        if self.branching_types_expression_str == "caa":
+            r01 = xp.sqrt(xs[0] * xs[0] + xs[1] * xs[1])
+            r23 = xp.sqrt(xs[2] * xs[2] + xs[3] * xs[3])
+            return {"r": xp.sqrt(r01 * r01 + r23 * r23), 0: xp.arctan2(r23, r01), 1: xp.arctan2(xs[1], xs[0]), 2: xp.arctan2(xs[3], xs[2])}
         if self.branching_types_expression_str in CANONICAL:
             base, perm = CANONICAL[self.branching_types_expression_str]
             sph = SphericalCoordinates(base).from_cartesian([xs[pi_] for pi_ in perm])
@@ -147,7 +161,7 @@ def harm_count(branching_types: str, n_end: int) -> int:
         return 2 * n_end - 1
     if branching_types == "ba":
         return n_end * n_end
-    if branching_types == "bba":
+    if branching_types in ("bba", "caa"):
         return n_end * (n_end + 1) * (2 * n_end + 1) // 6
     raise NotImplementedError(branching_types)
 

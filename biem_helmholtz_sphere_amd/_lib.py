@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libbiem_mi355.so")
 
 BIEM_OK = 0
-TREE_IDS = {"a": 0, "ba": 1, "bba": 2}
+TREE_IDS = {"a": 0, "ba": 1, "bba": 2, "caa": 3}
 FILL_REFERENCE, FILL_EQUILIBRATED = 0, 1
 USCAT_FAR_FIELD, USCAT_PER_BALL, USCAT_KIND_INNER, USCAT_POINTS_BATCHED = 1, 2, 4, 8
 

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 
 namespace biem {
 
@@ -56,8 +57,13 @@ static void make_labels(int tree, int n, std::vector<int>& lab, std::vector<int>
     for (int m = -(n - 1); m < 0; ++m) push(m, 0, 0, -m);
   } else if (tree == TREE_BA) {
     for (int q = 0; q < n; ++q) for (int m = -q; m <= q; ++m) push(q, m, 0, q);
-  } else {
+  } else if (tree == TREE_BBA) {
     for (int q = 0; q < n; ++q) for (int l = 0; l <= q; ++l) for (int m = -l; m <= l; ++m) push(q, l, m, q);
+  } else {  // caa: (n, m1, m2), n - |m1| - |m2| even >= 0
+    for (int q = 0; q < n; ++q)
+      for (int m1 = -q; m1 <= q; ++m1)
+        for (int m2 = -(q - (m1 < 0 ? -m1 : m1)); m2 <= q - (m1 < 0 ? -m1 : m1); ++m2)
+          if (((q - (m1 < 0 ? -m1 : m1) - (m2 < 0 ? -m2 : m2)) & 1) == 0) push(q, m1, m2, q);
   }
 }
 
@@ -94,7 +100,7 @@ struct Gaunt3 {
 };
 
 int plan_build_host(biem_plan* p, int tree, int n_end) {
-  if (tree < 0 || tree > 2) { set_error("unsupported coordinate tree id %d (built: a, ba, bba)", tree); return BIEM_ERR_UNSUPPORTED; }
+  if (tree < 0 || tree > 3) { set_error("unsupported coordinate tree id %d (built: a, ba, bba, caa)", tree); return BIEM_ERR_UNSUPPORTED; }
   if (n_end < 1 || n_end > 4096) { set_error("n_end=%d out of range", n_end); return BIEM_ERR_ARG; }
   p->tree = tree; p->d = tree_dim(tree); p->n_end = n_end; p->n2 = 2 * n_end - 1;
   p->H = harm_count(tree, n_end); p->H2 = harm_count(tree, p->n2);
@@ -119,6 +125,19 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
         int q = i * na + j; double ph = j * kPi / n, s = sqrt(1.0 - t0[i] * t0[i]);
         p->qy[3 * q] = t0[i]; p->qy[3 * q + 1] = s * cos(ph); p->qy[3 * q + 2] = s * sin(ph);
         p->qw[q] = w0[i] * kPi / n;
+      }
+    } else if (tree == TREE_CAA) {
+      // type-c root over two type-a children: sin t cos t dt = dx / 4 with x = cos 2t -> Gauss-Legendre in x (pinned by the
+      // jascome caa goldens); both azimuths 2 n_end equispaced points
+      gauss_legendre(n, t0, w0);
+      p->Q = n * na * na;
+      p->qy.resize((size_t)p->Q * d); p->qw.resize(p->Q);
+      for (int i = 0; i < n; ++i) for (int j1 = 0; j1 < na; ++j1) for (int j2 = 0; j2 < na; ++j2) {
+        int q = (i * na + j1) * na + j2;
+        double th = 0.5 * acos(t0[i]), p1 = j1 * kPi / n, p2 = j2 * kPi / n;
+        p->qy[4 * q] = cos(th) * cos(p1); p->qy[4 * q + 1] = cos(th) * sin(p1);
+        p->qy[4 * q + 2] = sin(th) * cos(p2); p->qy[4 * q + 3] = sin(th) * sin(p2);
+        p->qw[q] = 0.25 * w0[i] * (kPi / n) * (kPi / n);
       }
     } else {
       gauss_cheb2(n, t0, w0); gauss_legendre(n, t1, w1);
@@ -163,6 +182,40 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
         double g = G(qp, mp, q, m, q2);
         p->coef.push_back(isign_even(q + q2 - qp) * g);
         p->tidx.push_back(q2 * q2 + q2 + mu);
+      }
+      p->ptr[(size_t)h * H + hp + 1] = (uint32_t)p->coef.size();
+    }
+  } else if (tree == TREE_CAA) {
+    // int Y' conj(Y) conj(Y'') = delta(m1'' = m1' - m1) delta(m2'' = m2' - m2) / (2 pi) * int cbar' cbar cbar'' sin cos dt;
+    // the polar integrand is a polynomial of degree <= 2 n_end - 2 in x = cos 2t: Gauss-Legendre with 2 n_end nodes is exact
+    const int n2 = p->n2, nq = 2 * n;
+    std::vector<double> xg, wg; gauss_legendre(nq, xg, wg);
+    std::map<int, std::vector<double>> cb;      // key (n, a, b) -> values at the nodes
+    auto key = [](int q, int a, int b) { return (q * 256 + a) * 256 + b; };
+    for (size_t l = 0; l < p->deg2.size(); ++l) {
+      int q = p->labels2[3 * l], a = iabs(p->labels2[3 * l + 1]), b = iabs(p->labels2[3 * l + 2]);
+      auto& v = cb[key(q, a, b)];
+      if (!v.empty()) continue;
+      v.resize(nq);
+      for (int i = 0; i < nq; ++i) { double th = 0.5 * acos(xg[i]); v[i] = cbar_single(q, a, b, cos(th), sin(th)); }
+    }
+    std::map<int, int> pos2;                    // signed label -> index among degrees < n2
+    auto skey = [](int q, int m1, int m2) { return (q * 256 + (m1 + 128)) * 256 + (m2 + 128); };
+    for (size_t l = 0; l < p->deg2.size(); ++l) pos2[skey(p->labels2[3 * l], p->labels2[3 * l + 1], p->labels2[3 * l + 2])] = (int)l;
+    for (int h = 0; h < H; ++h) for (int hp = 0; hp < H; ++hp) {
+      int q = p->labels[3 * h], m1 = p->labels[3 * h + 1], m2 = p->labels[3 * h + 2];
+      int qp = p->labels[3 * hp], m1p = p->labels[3 * hp + 1], m2p = p->labels[3 * hp + 2];
+      int mu1 = m1p - m1, mu2 = m2p - m2;
+      const std::vector<double>& a = cb[key(qp, iabs(m1p), iabs(m2p))];
+      const std::vector<double>& b = cb[key(q, iabs(m1), iabs(m2))];
+      for (int q2 = iabs(q - qp); q2 <= q + qp; q2 += 2) {
+        if (q2 < iabs(mu1) + iabs(mu2)) continue;
+        const std::vector<double>& c = cb[key(q2, iabs(mu1), iabs(mu2))];
+        double acc = 0.0;
+        for (int i = 0; i < nq; ++i) acc += 0.25 * wg[i] * a[i] * b[i] * c[i];
+        if (fabs(acc) < 1e-14) continue;
+        p->coef.push_back(isign_even(q + q2 - qp) * acc / (2.0 * kPi));
+        p->tidx.push_back(pos2[skey(q2, mu1, mu2)]);
       }
       p->ptr[(size_t)h * H + hp + 1] = (uint32_t)p->coef.size();
     }

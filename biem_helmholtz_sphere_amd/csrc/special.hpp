@@ -17,9 +17,9 @@ constexpr double kEulerGamma = 0.57721566490153286061;
 constexpr double kSqrtHalfPi = 1.25331413731550025121;   // sqrt(pi/2)
 constexpr double kInvSqrt2Pi = 0.39894228040143267794;   // 1/sqrt(2 pi)
 
-enum Tree { TREE_A = 0, TREE_BA = 1, TREE_BBA = 2 };
+enum Tree { TREE_A = 0, TREE_BA = 1, TREE_BBA = 2, TREE_CAA = 3 };
 
-BIEM_HD int tree_dim(int tree) { return tree == TREE_A ? 2 : (tree == TREE_BA ? 3 : 4); }
+BIEM_HD int tree_dim(int tree) { return tree == TREE_A ? 2 : (tree == TREE_BA ? 3 : 4); }   // bba, caa: 4
 
 // number of harmonics of degree < n
 BIEM_HD int harm_count(int tree, int n) {
@@ -169,15 +169,47 @@ BIEM_HD double gbar_single(int k, int l, double x) {
 
 // Angles of a direction for the harmonics of one tree (computed once per direction).
 struct Dir {
-  double c0, s0;     // root polar angle (ba, bba)
+  double c0, s0;     // root polar angle (ba, bba, caa)
   double c1, s1;     // second polar angle (bba)
-  double phi;        // azimuth
+  double phi;        // azimuth (caa: azimuth of (x0, x1))
+  double phi2;       // caa: azimuth of (x2, x3)
 };
+
+// caa polar factor  cos^a sin^b Pbar_k^{(b,a)}(cos 2 theta),  k = (n-a-b)/2,  int_0^{pi/2} ()^2 sin cos dtheta = 1
+// (Hopf-type coordinates x0 = r cos t0 cos t1, x1 = r cos t0 sin t1, x2 = r sin t0 cos t2, x3 = r sin t0 sin t2; caa.svg)
+BIEM_HD double cbar_single(int n, int a, int b, double c, double s) {
+  const int k = (n - a - b) / 2;
+  const double x = c * c - s * s;
+  const double al = (double)b, be = (double)a;       // Jacobi P_k^{(alpha = b, beta = a)}
+  double p0 = 1.0, p1 = 1.0;
+  if (k >= 1) {
+    p1 = (al + 1.0) + 0.5 * (al + be + 2.0) * (x - 1.0);
+    for (int m = 1; m < k; ++m) {
+      double t = 2.0 * m + al + be;
+      double p2 = ((t + 1.0) * ((t + 2.0) * t * x + al * al - be * be) * p1 - 2.0 * (m + al) * (m + be) * (t + 2.0) * p0) /
+                  (2.0 * (m + 1.0) * (m + al + be + 1.0) * t);
+      p0 = p1; p1 = p2;
+    }
+  }
+  // norm^2 = 2 (2k+a+b+1) k! (k+a+b)! / ((k+a)! (k+b)!) = 2 (2k+a+b+1) prod_{i=1..a} (k+b+i)/(k+i)
+  double r = 2.0 * (2.0 * k + a + b + 1.0);
+  for (int i = 1; i <= a; ++i) r *= (double)(k + b + i) / (double)(k + i);
+  double f = sqrt(r);
+  for (int i = 0; i < a; ++i) f *= c;
+  for (int i = 0; i < b; ++i) f *= s;
+  return f * p1;
+}
 
 BIEM_HD Dir make_dir(int tree, const double* u) {
   Dir d;
-  d.c0 = 1.0; d.s0 = 0.0; d.c1 = 1.0; d.s1 = 0.0; d.phi = 0.0;
-  if (tree == TREE_A) {
+  d.c0 = 1.0; d.s0 = 0.0; d.c1 = 1.0; d.s1 = 0.0; d.phi = 0.0; d.phi2 = 0.0;
+  if (tree == TREE_CAA) {
+    double r01 = sqrt(u[0] * u[0] + u[1] * u[1]), r23 = sqrt(u[2] * u[2] + u[3] * u[3]);
+    double r = sqrt(r01 * r01 + r23 * r23);
+    if (r > 0.0) { d.c0 = r01 / r; d.s0 = r23 / r; }
+    d.phi = atan2(u[1], u[0]);
+    d.phi2 = atan2(u[3], u[2]);
+  } else if (tree == TREE_A) {
     d.phi = atan2(u[1], u[0]);
   } else if (tree == TREE_BA) {
     double rho = sqrt(u[1] * u[1] + u[2] * u[2]);
@@ -195,10 +227,17 @@ BIEM_HD Dir make_dir(int tree, const double* u) {
   return d;
 }
 
-// One harmonic Y_label(direction); label = (m,-,-) | (n,m,-) | (n,l,m).
+// One harmonic Y_label(direction); label = (m,-,-) | (n,m,-) | (n,l,m) | caa: (n,m1,m2).
 BIEM_HD void harmonic_single(int tree, int a, int b, int c, const Dir& d, double* re, double* im) {
   double amp;
   int m;
+  if (tree == TREE_CAA) {
+    amp = cbar_single(a, b < 0 ? -b : b, c < 0 ? -c : c, d.c0, d.s0) * (0.5 / kPi);
+    double ang = (double)b * d.phi + (double)c * d.phi2;
+    *re = amp * cos(ang);
+    *im = amp * sin(ang);
+    return;
+  }
   if (tree == TREE_A) {
     m = a;
     amp = kInvSqrt2Pi;

@@ -4,7 +4,7 @@ Mirrors the *configurations* of the reference's golden-generating commands (`jas
 cli.py:188-271: 2 balls at (0, +-2, 0..) or square grids of pitch 4, radius 1, eta = 1, sound-soft, plane wave along +x0
 with wavenumber 1.0 whatever the operator's k - reference quirk cli.py:238-244), not its CLI framework.
 
-    python -m biem_helmholtz_sphere_amd.sweep jascome  --out jascome_output.csv [--types a,ba,bpa,bba,bpbpa] [--n-end-max 9]
+    python -m biem_helmholtz_sphere_amd.sweep jascome  --out jascome_output.csv [--types a,ba,bpa,bba,bpbpa,caa] [--n-end-max 9]
     python -m biem_helmholtz_sphere_amd.sweep accuracy --out accuracy.csv --types ba --n-balls 2 --k 1,2,4 --n-end 1,2,3,4
 """
 from __future__ import annotations
@@ -73,7 +73,7 @@ def main(argv=None) -> None:
     sub = ap.add_subparsers(dest="cmd", required=True)
     j = sub.add_parser("jascome")
     j.add_argument("--out", default="jascome_output.csv")
-    j.add_argument("--types", default="a,ba,bpa,bba,bpbpa")
+    j.add_argument("--types", default="a,ba,bpa,bba,bpbpa,caa")
     j.add_argument("--n-end-max", type=int, default=9)
     j.add_argument("--device", default="cuda")
     a = sub.add_parser("accuracy")

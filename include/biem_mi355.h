@@ -41,6 +41,7 @@ extern "C" {
 #define BIEM_TREE_A 0    /* "a"   d=2 */
 #define BIEM_TREE_BA 1   /* "ba"  d=3, polar axis x0 */
 #define BIEM_TREE_BBA 2  /* "bba" d=4 */
+#define BIEM_TREE_CAA 3  /* "caa" d=4, Hopf-type: x0 = r cos t0 cos t1, x1 = r cos t0 sin t1, x2 = r sin t0 cos t2, x3 = r sin t0 sin t2 */
 
 /* fill scalings */
 #define BIEM_FILL_REFERENCE 0    /* A = blc_{n'} * { diag(alpha h + beta k h') | (S|R)^T (alpha j + beta k j') }  (_biem.py:745-792) */
@@ -70,7 +71,7 @@ int biem_plan_create(int tree, int n_end, biem_plan** plan);
 int biem_plan_destroy(biem_plan* plan);
 /* d, H (degree < n_end), Q quadrature points per ball, H2 (degree < 2 n_end - 1), number of translation terms */
 int biem_plan_info(const biem_plan* plan, int* d, int* n_harm, int* n_quad, int* n_harm2, long long* n_terms);
-/* h_labels[H][3]: a:(m,0,0)  ba:(n,m,0)  bba:(n,l,m);  h_deg[H]: degree n */
+/* h_labels[H][3]: a:(m,0,0)  ba:(n,m,0)  bba:(n,l,m)  caa:(n,m1,m2);  h_deg[H]: degree n */
 int biem_plan_labels(const biem_plan* plan, int* h_labels, int* h_deg);
 /* unit vectors y[Q][d] and weights w[Q] of the boundary-data rule (ush.expand(n=n_end)) */
 int biem_plan_quadrature(const biem_plan* plan, double* h_y, double* h_w);

@@ -124,6 +124,16 @@ def _gbar(kmax: int, lam: float, x: np.ndarray) -> np.ndarray:
     return p
 
 
+def _cbar(n: int, a: int, b: int, th: np.ndarray) -> np.ndarray:
+    """Polar factor of the caa harmonics: cos^a sin^b Pbar_k^{(b,a)}(cos 2 th), k = (n-a-b)/2, int_0^{pi/2} ()^2 sin cos dth = 1."""
+    k = (n - a - b) // 2
+    x = np.cos(2 * th)
+    # h = int (1-x)^b (1+x)^a P_k^2 dx ; norm^2 = 4 * 2^{a+b} / h
+    lg = math.lgamma
+    h = 2.0 ** (a + b + 1) / (2 * k + a + b + 1) * math.exp(lg(k + a + 1) + lg(k + b + 1) - lg(k + 1) - lg(k + a + b + 1))
+    return math.sqrt(4.0 * 2.0 ** (a + b) / h) * np.cos(th) ** a * np.sin(th) ** b * sp.eval_jacobi(k, b, a, x)
+
+
 def _gauss_legendre(n):
     t, w = sp.roots_legendre(n)
     return t, w
@@ -168,6 +178,9 @@ class Tree:
             return [(n, m) for n in range(n_end) for m in range(-n, n + 1)]
         if self.name == "bba":
             return [(n, l, m) for n in range(n_end) for l in range(n + 1) for m in range(-l, l + 1)]
+        if self.name == "caa":
+            return [(n, m1, m2) for n in range(n_end) for m1 in range(-n, n + 1) for m2 in range(-(n - abs(m1)), n - abs(m1) + 1)
+                    if (n - abs(m1) - abs(m2)) % 2 == 0]
         raise NotImplementedError(self.name)
 
     def degrees(self, n_end: int) -> np.ndarray:
@@ -213,6 +226,13 @@ class Tree:
             for h, (n, l, m) in enumerate(idx):
                 out[h] = (s0 ** l) * G[l][n - l] * Pb[l, abs(m)] * np.exp(1j * m * phi) / math.sqrt(2 * math.pi)
             return out
+        if self.name == "caa":
+            th0 = np.arctan2(np.hypot(u[:, 2], u[:, 3]), np.hypot(u[:, 0], u[:, 1]))
+            p1 = np.arctan2(u[:, 1], u[:, 0])
+            p2 = np.arctan2(u[:, 3], u[:, 2])
+            for h, (n, m1, m2) in enumerate(idx):
+                out[h] = _cbar(n, abs(m1), abs(m2), th0) * np.exp(1j * (m1 * p1 + m2 * p2)) / (2 * math.pi)
+            return out
         raise NotImplementedError(self.name)
 
     # ---- quadrature (the rule ush.expand(n=n_end) uses) -------------------------
@@ -241,10 +261,18 @@ class Tree:
             S1 = np.sqrt(1 - T1 * T1)
             y = np.stack([T0, S0 * T1, S0 * S1 * np.cos(PH), S0 * S1 * np.sin(PH)], axis=-1).reshape(-1, 4)
             return y, W.reshape(-1)
+        if self.name == "caa":
+            # type-c root over two type-a children: measure sin(t) cos(t) dt = dx / 4 with x = cos 2t -> Gauss-Legendre in x
+            xg, wg = _gauss_legendre(n)
+            th = 0.5 * np.arccos(xg)
+            TH, P1, P2 = np.meshgrid(th, phi, phi, indexing="ij")
+            W = (wg / 4.0)[:, None, None] * wphi[None, :, None] * wphi[None, None, :]
+            y = np.stack([np.cos(TH) * np.cos(P1), np.cos(TH) * np.sin(P1), np.sin(TH) * np.cos(P2), np.sin(TH) * np.sin(P2)], axis=-1)
+            return y.reshape(-1, 4), W.reshape(-1)
         raise NotImplementedError(self.name)
 
 
-_TREES = {"a": Tree("a", 2), "ba": Tree("ba", 3), "bba": Tree("bba", 4),
+_TREES = {"a": Tree("a", 2), "ba": Tree("ba", 3), "bba": Tree("bba", 4), "caa": Tree("caa", 4),
           "bpa": Tree("bpa", 3, "ba", (2, 1, 0)), "bpbpa": Tree("bpbpa", 4, "bba", (3, 1, 2, 0))}
 
 
@@ -432,7 +460,69 @@ def translation_SR(tr: Tree, n_end: int, k: float, t: np.ndarray) -> np.ndarray:
             # G3 table from _gaunt3(n_end) has l'' < 2 n_end - 1 as required
             SR[hp] = np.einsum("hnl,hl,nh,nlh->h", Kq, G3r, sign, Vg, optimize=True)
         return Cd * SR
+    if tr.name == "caa":
+        idx = tr.index(n_end)
+        idx2 = tr.index(n2)
+        pos2 = {lab: i for i, lab in enumerate(idx2)}
+        Yt = tr.harmonics(u[None, :], n2)[:, 0]
+        T = hn[tr.degrees(n2)] * Yt                                   # [H2]
+        I3 = _theta_c(n_end)
+        H = len(idx)
+        SR = np.zeros((H, H), dtype=np.complex128)
+        for hp, (np_, m1p, m2p) in enumerate(idx):
+            for h, (n, m1, m2) in enumerate(idx):
+                mu1, mu2 = m1p - m1, m2p - m2
+                acc = 0.0
+                for n3 in range(abs(n - np_), n + np_ + 1, 2):
+                    if n3 < abs(mu1) + abs(mu2):
+                        continue
+                    g = I3.get(np_, abs(m1p), abs(m2p), n, abs(m1), abs(m2), n3, abs(mu1), abs(mu2))
+                    acc = acc + np.real(1j ** ((n + n3 - np_) % 4)) * g * T[pos2[(n3, mu1, mu2)]]
+                SR[hp, h] = acc
+        return Cd * SR / (2 * math.pi)
     raise NotImplementedError(tr.name)
+
+
+@lru_cache(maxsize=4)
+def _theta_c(n_end: int):
+    """Polar triple integrals of caa: I[(n',a',b', n,a,b, n'')] = int cbar' cbar cbar'' sin cos dth with a'' = |m1'-m1| etc.
+    (all sign combinations share |m|'s, so the table is keyed by absolute values plus the implied a'', b'')."""
+    xg, wg = _gauss_legendre(2 * n_end)
+    th = 0.5 * np.arccos(xg)
+    w = wg / 4.0
+    tr = tree("caa")
+    labs = sorted({(n, abs(m1), abs(m2)) for (n, m1, m2) in tr.index(2 * n_end - 1)})
+    vals = {lab: _cbar(lab[0], lab[1], lab[2], th) for lab in labs}
+
+    class _Tab(dict):
+        def __missing__(self, key):
+            raise KeyError(key)
+
+    out = {}
+    small = [l for l in labs if l[0] < n_end]
+    idx = tr.index(n_end)
+    # only combinations that occur: (a'', b'') = (|m1' - m1|, |m2' - m2|) over signed m's
+    need = set()
+    for (np_, m1p, m2p) in idx:
+        for (n, m1, m2) in idx:
+            a3, b3 = abs(m1p - m1), abs(m2p - m2)
+            for n3 in range(abs(n - np_), n + np_ + 1, 2):
+                if n3 >= a3 + b3:
+                    need.add((np_, abs(m1p), abs(m2p), n, abs(m1), abs(m2), n3, a3, b3))
+    for (np_, ap, bp, n, a, b, n3, a3, b3) in need:
+        out[(np_, ap, bp, n, a, b, n3, a3, b3)] = float(np.sum(w * vals[(np_, ap, bp)] * vals[(n, a, b)] * vals[(n3, a3, b3)]))
+    return _CaaTable(out)
+
+
+class _CaaTable:
+    def __init__(self, d):
+        self.d = d
+
+    def __getitem__(self, key):
+        raise TypeError("use get()")
+
+    def get(self, np_, ap, bp, n, a, b, n3, a3, b3):
+        return self.d[(np_, ap, bp, n, a, b, n3, a3, b3)]
 
 
 def translation_SR_2d_graf(n_end: int, k: float, t: np.ndarray) -> np.ndarray:

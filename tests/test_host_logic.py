@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_plan_host_tables_without_gpu():
     lib = _lib.load()
-    for tree, n_end, H, Q in (("a", 6, 11, 12), ("ba", 6, 36, 72), ("bba", 4, 30, 128)):
+    for tree, n_end, H, Q in (("a", 6, 11, 12), ("ba", 6, 36, 72), ("bba", 4, 30, 128), ("caa", 3, 14, 108)):
         plan = C.c_void_p()
         _lib.check(lib.biem_plan_create_host(_lib.TREE_IDS[tree], n_end, C.byref(plan)))
         d, h, q, h2, nt = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_longlong()
@@ -97,14 +97,14 @@ def test_memory_guard_matches_reference_formulas():
 
 def test_coordinates_roundtrip_and_unsupported_tree():
     rng = np.random.default_rng(0)
-    for t in ("a", "ba", "bba", "bpa", "bpbpa"):
+    for t in ("a", "ba", "bba", "bpa", "bpbpa", "caa"):
         c = amd.create_from_branching_types(t)
         x = rng.normal(size=(c.c_ndim, 9))
         sph = c.from_cartesian(x)
         assert np.allclose(c.to_cartesian(sph, as_array=True), x)
         assert np.allclose(sph["r"], np.linalg.norm(x, axis=0))
-    with pytest.raises(NotImplementedError, match="planned"):
-        amd.create_from_branching_types("caa")
+    with pytest.raises(NotImplementedError, match="not built"):
+        amd.create_from_branching_types("cba")
     assert _coords.n_end_from_harm("bba", 385) == 10 and _coords.n_end_from_harm("a", 127) == 64
     # committed bpa.svg / bpbpa.svg axis conventions
     sph = {"r": np.asarray(2.0), 0: np.asarray(0.3), 1: np.asarray(1.1)}

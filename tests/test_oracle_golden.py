@@ -39,12 +39,12 @@ def test_jascome_triplet_rows(golden_dir):
     n = 0
     for r in _rows(golden_dir, "jascome_output.csv"):
         bt, n_end = r["branching_types"], int(r["n_end"])
-        if bt not in ("a", "ba", "bba", "bpa", "bpbpa") or n_end > 6:
+        if n_end > 6:
             continue
         u = _uscat0(bt, n_end, 1.0, O.grid_centers(0, O.tree(bt).d))
         assert abs(u - complex(r["uscat"])) < TRIPLET_TOL[n_end], (bt, n_end)
         n += 1
-    assert n == 30
+    assert n == 35      # all six branching types of the reference's driver: caa 1-5, the others 1-6
 
 
 def test_readme_doctest():
@@ -101,7 +101,7 @@ def test_translation_table_vs_quadrature_and_bruteforce():
     """Closed form (tabulated) == closed form (one quadrature) == brute-force projection of the
     translated singular function onto the sphere (convention-free definition)."""
     rng = np.random.default_rng(1)
-    for name in ("a", "ba", "bba"):
+    for name in ("a", "ba", "bba", "caa"):
         tr = O.tree(name)
         n_end, k, rho = 4, 1.3, 0.7
         t = rng.normal(size=tr.d)
