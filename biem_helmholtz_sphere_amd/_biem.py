@@ -537,9 +537,28 @@ def _boundary_samples(plan: _Plan, origin: _Origin, fl: _Flat, batch, uin, uin_g
     if uin_grad is not None:
         gu = _to_dev(uin_grad(xu), dev, torch.complex128)
         g = g - ab(fl.beta) * torch.sum(gu * x_rel.to(torch.complex128), dim=0)
-    # (...(f), B, ...batch) -> (nb, B, Q)
-    g = g.reshape((Q, B, nb))
-    return g.permute(2, 1, 0).contiguous()
+    # The incident field may vary along batch axes on which the operator (k, eta, geometry, alpha, beta) has size 1
+    # (e.g. many incidence directions for one wavenumber): those axes become right-hand sides of ONE factorisation.
+    # The reference broadcasts the matrix over them in btensorsolve (_biem.py:797), i.e. factors it again per incidence.
+    nq = len(qshape)
+    full = tuple(g.shape[nq + 1:])
+    if len(full) != nbt:
+        raise ValueError(f"uin/uin_grad returned an array with batch shape {full}, expected {nbt} batch axes like k")
+    op_axes = [i for i in range(nbt) if batch[i] == full[i]]
+    rhs_axes = [i for i in range(nbt) if batch[i] != full[i]]
+    nrhs = int(np.prod([full[i] for i in rhs_axes])) if rhs_axes else 1
+    g = g.reshape((Q, B) + full)
+    g = g.permute([2 + i for i in op_axes] + [2 + i for i in rhs_axes] + [1, 0])      # (*op, *rhs, B, Q)
+    return g.reshape(nb, nrhs, B, Q).contiguous(), full, op_axes, rhs_axes
+
+
+def _restore_batch(t: torch.Tensor, full, op_axes, rhs_axes) -> torch.Tensor:
+    """[nb, nrhs, ...] in (op axes, rhs axes) order -> (*full, ...) in the caller's axis order."""
+    tail = tuple(t.shape[2:])
+    t = t.reshape(tuple(full[i] for i in op_axes) + tuple(full[i] for i in rhs_axes) + tail)
+    order = op_axes + rhs_axes
+    inv = [order.index(i) for i in range(len(full))]
+    return t.permute(inv + [len(full) + j for j in range(len(tail))])
 
 
 def biem(
@@ -588,12 +607,14 @@ def biem(
 
     has_rhs = not (uin is None and uin_grad is None)
     g = None
+    full, op_axes, rhs_axes, nrhs = tuple(batch), list(range(len(batch))), [], 1
     if has_rhs:
         if not bool(torch.all(alpha_t == 0)) and uin is None:
             raise ValueError("alpha is not zero, but uin is None. uin must be provided to compute the boundary condition.")
         if not bool(torch.all(beta_t == 0)) and uin_grad is None:
             raise ValueError("beta is not zero, but uin_grad is None. uin_grad must be provided to compute the boundary condition.")
-        g = _boundary_samples(plan, origin, fl, batch, uin, uin_grad, perm)
+        g, full, op_axes, rhs_axes = _boundary_samples(plan, origin, fl, batch, uin, uin_grad, perm)
+        nrhs = int(g.shape[1])
 
     use_matrix = (not has_rhs) or B > 1 or force_matrix          # reference :643-645
     density_t = None
@@ -603,16 +624,17 @@ def biem(
             tab = torch.empty((nb, B, 3, n_end), dtype=torch.complex128, device=dev)
             L.check(lib.biem_ball_tables(plan.handle, nb, B, _ptr(fl.k), _ptr(fl.eta), _ptr(fl.radii), fl.geom_batched,
                                          _ptr(fl.alpha), _ptr(fl.beta), fl.ab_batched, _ptr(tab), sp), "biem_ball_tables")
-            f = torch.empty((nb, B * H), dtype=torch.complex128, device=dev)
-            L.check(lib.biem_rhs_project(plan.handle, nb, B, _ptr(g), _ptr(f), B * H, 1, sp), "biem_rhs_project")
-            density_t = torch.empty((nb, B, H), dtype=torch.complex128, device=dev)
-            L.check(lib.biem_density(plan.handle, nb, B, _ptr(f), B * H, 1, _ptr(tab), _ptr(density_t), sp), "biem_density")
+            f = torch.empty((nb, nrhs, B * H), dtype=torch.complex128, device=dev)
+            L.check(lib.biem_rhs_project(plan.handle, nb, B, nrhs, _ptr(g), _ptr(f), nrhs * B * H, 1, B * H, sp), "biem_rhs_project")
+            density_t = torch.empty((nb, nrhs, B, H), dtype=torch.complex128, device=dev)
+            L.check(lib.biem_density(plan.handle, nb, B, nrhs, _ptr(f), nrhs * B * H, 1, B * H, _ptr(tab), _ptr(density_t), sp),
+                    "biem_density")
         elif has_rhs:
-            wbytes = int(lib.biem_solve_workspace_bytes(plan.handle, nb, B, int(chunk)))
+            wbytes = int(lib.biem_solve_workspace_bytes(plan.handle, nb, B, nrhs, int(chunk)))
             work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
-            density_t = torch.empty((nb, B, H), dtype=torch.complex128, device=dev)
+            density_t = torch.empty((nb, nrhs, B, H), dtype=torch.complex128, device=dev)
             info = torch.zeros(nb, dtype=torch.int32, device=dev)
-            L.check(lib.biem_solve(plan.handle, nb, B, _ptr(fl.k), _ptr(fl.eta), _ptr(fl.centers), _ptr(fl.radii), fl.geom_batched,
+            L.check(lib.biem_solve(plan.handle, nb, B, nrhs, _ptr(fl.k), _ptr(fl.eta), _ptr(fl.centers), _ptr(fl.radii), fl.geom_batched,
                                    _ptr(fl.alpha), _ptr(fl.beta), fl.ab_batched, _ptr(g), _ptr(density_t), _ptr(info), int(chunk),
                                    _ptr(work), wbytes, sp), "biem_solve")
             del work
@@ -631,7 +653,7 @@ def biem(
             return origin.give(A.reshape(tuple(batch) + (B, H, B, H)))
 
     matrix = make_matrix if use_matrix else None
-    density = None if density_t is None else origin.give(density_t.reshape(tuple(batch) + (B, H)))
+    density = None if density_t is None else origin.give(_restore_batch(density_t, full, op_axes, rhs_axes).contiguous())
 
     if uin is None:
         uin_wrapped = None

@@ -35,17 +35,17 @@ SIGNATURES = {
     "biem_radial": (_i, [_i, _i, _i, _dp, _dp, _vp]),
     "biem_harmonics": (_i, [_vp, _i, _dp, _dp, _vp]),
     "biem_ball_tables": (_i, [_vp, _i, _i, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _vp]),
-    "biem_rhs_project": (_i, [_vp, _i, _i, _dp, _dp, _ll, _ll, _vp]),
+    "biem_rhs_project": (_i, [_vp, _i, _i, _i, _dp, _dp, _ll, _ll, _ll, _vp]),
     "biem_fill_workspace_bytes": (_sz, [_vp, _i, _i]),
     "biem_fill": (_i, [_vp, _i, _i, _dp, _dp, _i, _dp, _i, _dp, _ll, _ll, _i, _vp, _sz, _vp]),
     "biem_lu_npad": (_i, [_i]),
     "biem_lu_workspace_bytes": (_sz, [_i, _i, _i]),
     "biem_lu_factor_solve": (_i, [_i, _i, _i, _dp, _ll, _ll, _ip, _ip, _vp, _sz, _vp]),
-    "biem_density": (_i, [_vp, _i, _i, _dp, _ll, _ll, _dp, _dp, _vp]),
+    "biem_density": (_i, [_vp, _i, _i, _i, _dp, _ll, _ll, _ll, _dp, _dp, _vp]),
     "biem_uscat_workspace_bytes": (_sz, [_vp, _i, _i]),
     "biem_uscat": (_i, [_vp, _i, _i, _i, _dp, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _vp, _sz, _vp]),
-    "biem_solve_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
-    "biem_solve": (_i, [_vp, _i, _i, _dp, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _dp, _ip, _i, _vp, _sz, _vp]),
+    "biem_solve_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
+    "biem_solve": (_i, [_vp, _i, _i, _i, _dp, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _dp, _ip, _i, _vp, _sz, _vp]),
     "biem_profile_begin": (_i, []),
     "biem_profile_end": (_i, [_vp, _vp, _vp]),
     "biem_bench_mfma_f64": (_i, [_i, C.POINTER(C.c_double), _vp]),

@@ -118,10 +118,10 @@ int biem_ball_tables(const biem_plan* plan, int nb, int B, const double* d_k, co
   return launch_ball_tables(plan, nb, B, d_k, d_eta, d_radii, geom_batched, d_alpha, d_beta, ab_batched, d_tab, (hipStream_t)stream);
 }
 
-int biem_rhs_project(const biem_plan* plan, int nb, int B, const double* d_g, double* d_f, long long sys_stride,
-                     long long elem_stride, void* stream) {
+int biem_rhs_project(const biem_plan* plan, int nb, int B, int nrhs, const double* d_g, double* d_f, long long sys_stride,
+                     long long elem_stride, long long rhs_stride, void* stream) {
   NEED_DEV(plan); NEED(d_g, "d_g"); NEED(d_f, "d_f");
-  return launch_rhs_project(plan, nb, B, d_g, d_f, sys_stride, elem_stride, (hipStream_t)stream);
+  return launch_rhs_project(plan, nb, B, nrhs, d_g, d_f, sys_stride, elem_stride, rhs_stride, (hipStream_t)stream);
 }
 
 size_t biem_fill_workspace_bytes(const biem_plan* plan, int nb, int B) { return plan ? fill_workspace_bytes(plan, nb, B) : 0; }
@@ -144,10 +144,10 @@ int biem_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda
   return launch_lu_factor_solve(nb, n_pad, nrhs, d_A, lda, sys_stride, d_ipiv, d_info, d_work, work_bytes, (hipStream_t)stream);
 }
 
-int biem_density(const biem_plan* plan, int nb, int B, const double* d_x, long long sys_stride, long long elem_stride,
-                 const double* d_tab, double* d_density, void* stream) {
+int biem_density(const biem_plan* plan, int nb, int B, int nrhs, const double* d_x, long long sys_stride, long long elem_stride,
+                 long long rhs_stride, const double* d_tab, double* d_density, void* stream) {
   NEED_DEV(plan); NEED(d_x, "d_x"); NEED(d_tab, "d_tab"); NEED(d_density, "d_density");
-  return launch_density(plan, nb, B, d_x, sys_stride, elem_stride, d_tab, d_density, (hipStream_t)stream);
+  return launch_density(plan, nb, B, nrhs, d_x, sys_stride, elem_stride, rhs_stride, d_tab, d_density, (hipStream_t)stream);
 }
 
 size_t biem_uscat_workspace_bytes(const biem_plan* plan, int nb, int B) {
@@ -171,15 +171,15 @@ struct SolveLayout {
   size_t off_tab, off_A, off_T, off_P, off_ipiv, total;
 };
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-SolveLayout make_layout(const biem_plan* p, int nb, int B, int chunk) {
+SolveLayout make_layout(const biem_plan* p, int nb, int B, int nrhs, int chunk) {
   SolveLayout L;
   L.N = B * p->H;
   L.n_pad = lu_npad(L.N);
-  L.lda = L.n_pad + 8;              // one right-hand side column; rows stay 128-byte aligned (8 complex128)
+  L.lda = L.n_pad + ((nrhs + 7) / 8) * 8;   // right-hand side columns; rows stay 128-byte aligned (8 complex128)
   L.sys_stride = (long long)L.n_pad * L.lda;
   if (chunk <= 0) {
     // resident matrices per chunk: as many as fit ~24 GiB, at most nb
-    size_t per = (size_t)L.sys_stride * 16 + (size_t)B * B * p->H2 * 16 + lu_workspace_bytes(1, L.n_pad, 1);
+    size_t per = (size_t)L.sys_stride * 16 + (size_t)B * B * p->H2 * 16 + lu_workspace_bytes(1, L.n_pad, nrhs);
     size_t fit = ((size_t)24 << 30) / (per ? per : 1);
     chunk = (int)(fit < 1 ? 1 : (fit > (size_t)nb ? (size_t)nb : fit));
   }
@@ -189,26 +189,27 @@ SolveLayout make_layout(const biem_plan* p, int nb, int B, int chunk) {
   L.off_tab = o; o = align256(o + (size_t)nb * B * 3 * p->n_end * 16);
   L.off_A = o; o = align256(o + (size_t)chunk * L.sys_stride * 16);
   L.off_T = o; o = align256(o + fill_workspace_bytes(p, chunk, B));
-  L.off_P = o; o = align256(o + lu_workspace_bytes(chunk, L.n_pad, 1));
+  L.off_P = o; o = align256(o + lu_workspace_bytes(chunk, L.n_pad, nrhs));
   L.off_ipiv = o; o = align256(o + (size_t)chunk * L.n_pad * sizeof(int));
   L.total = o;
   return L;
 }
 }  // namespace
 
-size_t biem_solve_workspace_bytes(const biem_plan* plan, int nb, int B, int chunk) {
-  if (!plan || nb <= 0 || B <= 0) return 0;
-  return make_layout(plan, nb, B, chunk).total;
+size_t biem_solve_workspace_bytes(const biem_plan* plan, int nb, int B, int nrhs, int chunk) {
+  if (!plan || nb <= 0 || B <= 0 || nrhs < 1) return 0;
+  return make_layout(plan, nb, B, nrhs, chunk).total;
 }
 
-int biem_solve(const biem_plan* plan, int nb, int B, const double* d_k, const double* d_eta, const double* d_centers,
+int biem_solve(const biem_plan* plan, int nb, int B, int nrhs, const double* d_k, const double* d_eta, const double* d_centers,
                const double* d_radii, int geom_batched, const double* d_alpha, const double* d_beta, int ab_batched,
                const double* d_g, double* d_density, int* d_info, int chunk, void* d_work, size_t work_bytes, void* stream) {
   NEED_DEV(plan); NEED(d_k, "d_k"); NEED(d_eta, "d_eta"); NEED(d_centers, "d_centers"); NEED(d_radii, "d_radii");
   NEED(d_alpha, "d_alpha"); NEED(d_beta, "d_beta"); NEED(d_g, "d_g"); NEED(d_density, "d_density"); NEED(d_info, "d_info"); NEED(d_work, "d_work");
   if (nb <= 0 || B <= 0) return BIEM_OK;
+  if (nrhs < 1) { set_error("biem_solve: nrhs < 1"); return BIEM_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
-  SolveLayout L = make_layout(plan, nb, B, chunk);
+  SolveLayout L = make_layout(plan, nb, B, nrhs, chunk);
   if (work_bytes < L.total) { set_error("biem_solve: workspace too small (%zu < %zu)", work_bytes, L.total); return BIEM_ERR_ARG; }
   char* w = (char*)d_work;
   double* tab = (double*)(w + L.off_tab);
@@ -230,11 +231,11 @@ int biem_solve(const biem_plan* plan, int nb, int B, const double* d_k, const do
     if (rc) return rc;
     BIEM_HIPCHK(hipMemset2DAsync(A + (size_t)L.n_pad * 2, (size_t)L.lda * 16, 0, (size_t)(L.lda - L.n_pad) * 16,
                                  (size_t)L.n_pad * c, st));
-    rc = launch_rhs_project(plan, c, B, d_g + (size_t)s0 * B * Q * 2, A + (size_t)L.n_pad * 2, L.sys_stride, L.lda, st);
+    rc = launch_rhs_project(plan, c, B, nrhs, d_g + (size_t)s0 * nrhs * B * Q * 2, A + (size_t)L.n_pad * 2, L.sys_stride, L.lda, 1, st);
     if (rc) return rc;
-    rc = launch_lu_factor_solve(c, L.n_pad, 1, A, L.lda, L.sys_stride, ipiv, d_info + s0, Pw, lu_workspace_bytes(c, L.n_pad, 1), st);
+    rc = launch_lu_factor_solve(c, L.n_pad, nrhs, A, L.lda, L.sys_stride, ipiv, d_info + s0, Pw, lu_workspace_bytes(c, L.n_pad, nrhs), st);
     if (rc) return rc;
-    rc = launch_density(plan, c, B, A + (size_t)L.n_pad * 2, L.sys_stride, L.lda, tb, d_density + (size_t)s0 * B * H * 2, st);
+    rc = launch_density(plan, c, B, nrhs, A + (size_t)L.n_pad * 2, L.sys_stride, L.lda, 1, tb, d_density + (size_t)s0 * nrhs * B * H * 2, st);
     if (rc) return rc;
   }
   return BIEM_OK;

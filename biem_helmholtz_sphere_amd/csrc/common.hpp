@@ -71,14 +71,14 @@ int launch_radial(int d, int nmax, int count, const double* d_x, double* d_out, 
 int launch_harmonics(const biem_plan* p, int count, const double* d_u, double* d_Y, hipStream_t st);
 int launch_ball_tables(const biem_plan* p, int nb, int B, const double* d_k, const double* d_eta, const double* d_radii,
                        int geom_batched, const double* d_alpha, const double* d_beta, int ab_batched, double* d_tab, hipStream_t st);
-int launch_rhs_project(const biem_plan* p, int nb, int B, const double* d_g, double* d_f, long long sys_stride,
-                       long long elem_stride, hipStream_t st);
+int launch_rhs_project(const biem_plan* p, int nb, int B, int nrhs, const double* d_g, double* d_f, long long sys_stride,
+                       long long elem_stride, long long rhs_stride, hipStream_t st);
 size_t fill_workspace_bytes(const biem_plan* p, int nb, int B);
 int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const double* d_centers, int geom_batched,
                 const double* d_tab, int scaling, double* d_A, long long lda, long long sys_stride, int n_pad,
                 void* d_work, size_t work_bytes, hipStream_t st);
-int launch_density(const biem_plan* p, int nb, int B, const double* d_x, long long sys_stride, long long elem_stride,
-                   const double* d_tab, double* d_density, hipStream_t st);
+int launch_density(const biem_plan* p, int nb, int B, int nrhs, const double* d_x, long long sys_stride, long long elem_stride,
+                   long long rhs_stride, const double* d_tab, double* d_density, hipStream_t st);
 int launch_uscat(const biem_plan* p, int nb, int B, int P, const double* d_k, const double* d_eta, const double* d_centers,
                  const double* d_radii, int geom_batched, const double* d_density, const double* d_points, int flags,
                  double* d_out, void* d_work, size_t work_bytes, hipStream_t st);

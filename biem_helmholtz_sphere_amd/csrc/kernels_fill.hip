@@ -288,9 +288,9 @@ int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const doub
 // block = RT rows x 256 columns; g rows staged in LDS, W streamed coalesced along h.
 // ---------------------------------------------------------------------------------------------
 template <int RT>
-__global__ void __launch_bounds__(256) k_rhs_project(int H, int Q, int rows, int B, const cplx* __restrict__ g,
+__global__ void __launch_bounds__(256) k_rhs_project(int H, int Q, int rows, int B, int nrhs, const cplx* __restrict__ g,
                                                       const cplx* __restrict__ W, cplx* __restrict__ f, long long sys_stride,
-                                                      long long elem_stride) {
+                                                      long long elem_stride, long long rhs_stride) {
   extern __shared__ cplx sg[];   // [RT][QC]
   constexpr int QC = 256;
   int row0 = blockIdx.y * RT;
@@ -317,21 +317,22 @@ __global__ void __launch_bounds__(256) k_rhs_project(int H, int Q, int rows, int
     for (int r = 0; r < RT; ++r) {
       int row = row0 + r;
       if (row >= rows) break;
-      long long s = row / B, b = row % B;
-      f[(size_t)s * sys_stride + ((size_t)b * H + h) * elem_stride] = acc[r];
+      long long b = row % B, sr = row / B, rr = sr % nrhs, s = sr / nrhs;     // row = (s*nrhs + rr)*B + b
+      f[(size_t)s * sys_stride + ((size_t)b * H + h) * elem_stride + (size_t)rr * rhs_stride] = acc[r];
     }
   }
 }
 
-int launch_rhs_project(const biem_plan* p, int nb, int B, const double* d_g, double* d_f, long long sys_stride,
-                       long long elem_stride, hipStream_t st) {
-  int rows = nb * B;
+int launch_rhs_project(const biem_plan* p, int nb, int B, int nrhs, const double* d_g, double* d_f, long long sys_stride,
+                       long long elem_stride, long long rhs_stride, hipStream_t st) {
+  if (nrhs < 1) { set_error("biem_rhs_project: nrhs < 1"); return BIEM_ERR_ARG; }
+  int rows = nb * nrhs * B;
   if (rows <= 0) return BIEM_OK;
   constexpr int RT = 8;
   size_t shm = (size_t)RT * 256 * sizeof(cplx);
   ProfScope ps(PK_RHS, st, 8.0 * (double)rows * p->Q * p->H);
   hipLaunchKernelGGL(k_rhs_project<RT>, dim3((p->H + 255) / 256, (rows + RT - 1) / RT), dim3(256), shm, st, p->H, p->Q, rows, B,
-                     (const cplx*)d_g, (const cplx*)p->d_W, (cplx*)d_f, sys_stride, elem_stride);
+                     nrhs, (const cplx*)d_g, (const cplx*)p->d_W, (cplx*)d_f, sys_stride, elem_stride, rhs_stride);
   BIEM_LAUNCHCHK();
   return BIEM_OK;
 }
@@ -339,25 +340,27 @@ int launch_rhs_project(const biem_plan* p, int nb, int B, const double* d_g, dou
 // ---------------------------------------------------------------------------------------------
 // density = x / (gh * blc)   (reference scaling of the unknown; single-ball shortcut _biem.py:673-690 with x = f)
 // ---------------------------------------------------------------------------------------------
-__global__ void k_density(int H, int n_end, int B, long long total, const int* __restrict__ deg, const cplx* __restrict__ x,
-                          long long sys_stride, long long elem_stride, const cplx* __restrict__ tab, cplx* __restrict__ dens) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_density(int H, int n_end, int B, int nrhs, long long total, const int* __restrict__ deg, const cplx* __restrict__ x,
+                          long long sys_stride, long long elem_stride, long long rhs_stride, const cplx* __restrict__ tab,
+                          cplx* __restrict__ dens) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // i = ((s*nrhs + r)*B + b)*H + h
   if (i >= total) return;
   int h = (int)(i % H);
-  long long sb = i / H;
-  long long s = sb / B, b = sb % B;
+  long long srb = i / H;
+  long long b = srb % B, sr = srb / B, r = sr % nrhs, s = sr / nrhs;
   int n = deg[h];
-  const cplx* t = tab + (size_t)sb * 3 * n_end;
-  cplx v = x[(size_t)s * sys_stride + ((size_t)b * H + h) * elem_stride];
+  const cplx* t = tab + (size_t)(s * B + b) * 3 * n_end;
+  cplx v = x[(size_t)s * sys_stride + ((size_t)b * H + h) * elem_stride + (size_t)r * rhs_stride];
   dens[i] = cmul(v, crecip(cmul(t[n_end + n], t[2 * n_end + n])));
 }
 
-int launch_density(const biem_plan* p, int nb, int B, const double* d_x, long long sys_stride, long long elem_stride,
-                   const double* d_tab, double* d_density, hipStream_t st) {
-  long long total = (long long)nb * B * p->H;
+int launch_density(const biem_plan* p, int nb, int B, int nrhs, const double* d_x, long long sys_stride, long long elem_stride,
+                   long long rhs_stride, const double* d_tab, double* d_density, hipStream_t st) {
+  if (nrhs < 1) { set_error("biem_density: nrhs < 1"); return BIEM_ERR_ARG; }
+  long long total = (long long)nb * nrhs * B * p->H;
   if (total <= 0) return BIEM_OK;
-  hipLaunchKernelGGL(k_density, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p->H, p->n_end, B, total, p->d_deg,
-                     (const cplx*)d_x, sys_stride, elem_stride, (const cplx*)d_tab, (cplx*)d_density);
+  hipLaunchKernelGGL(k_density, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p->H, p->n_end, B, nrhs, total, p->d_deg,
+                     (const cplx*)d_x, sys_stride, elem_stride, rhs_stride, (const cplx*)d_tab, (cplx*)d_density);
   BIEM_LAUNCHCHK();
   return BIEM_OK;
 }

@@ -95,10 +95,11 @@ int biem_ball_tables(const biem_plan* plan, int nb, int B, const double* d_k, co
                      int ab_batched, double* d_tab, void* stream);
 
 /* ---- right-hand side (ush.expand, _biem.py:627-639): the incident field stays a Python callable; only its samples
- *      g[row][q] = (-alpha u_in - beta d_n u_in)(c_b + rho_b y_q), row = s*B + b, cross the ABI.
- *      f element (row, h) is written to d_f[(row / B) * sys_stride + ((row % B) * H + h) * elem_stride]  (complex128 units) ---- */
-int biem_rhs_project(const biem_plan* plan, int nb, int B, const double* d_g /*[nb*B][Q] c128*/, double* d_f,
-                     long long sys_stride, long long elem_stride, void* stream);
+ *      g[s][r][b][q] = (-alpha u_in - beta d_n u_in)(c_b + rho_b y_q) cross the ABI; r = 0..nrhs-1 are right-hand sides that
+ *      share system s (incidences on which k, eta, the geometry and alpha/beta do not depend: factor once, solve many).
+ *      f element (s, r, b, h) is written to d_f[s*sys_stride + (b*H + h)*elem_stride + r*rhs_stride]  (complex128 units) ---- */
+int biem_rhs_project(const biem_plan* plan, int nb, int B, int nrhs, const double* d_g /*[nb][nrhs][B][Q] c128*/, double* d_f,
+                     long long sys_stride, long long elem_stride, long long rhs_stride, void* stream);
 
 /* ---- matrix fill (ush.harmonics_translation_coef + the where/create_diagonal/moveaxis block, _biem.py:694-792) ----
  * Writes the N x N matrix of every system, row-major [b][h][b'][h'] with leading dimension lda (complex128 units),
@@ -120,10 +121,10 @@ size_t biem_lu_workspace_bytes(int nb, int n_pad, int nrhs);
 int biem_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride,
                          int* d_ipiv /*[nb][n_pad]*/, int* d_info /*[nb]*/, void* d_work, size_t work_bytes, void* stream);
 
-/* density[s][b][h] = x / (gh * blc): the reference's `density` from the equilibrated unknowns (also the
- * single-ball shortcut _biem.py:648-691 with x = f).  x element (s, i) at d_x[s*sys_stride + i*elem_stride]. */
-int biem_density(const biem_plan* plan, int nb, int B, const double* d_x, long long sys_stride, long long elem_stride,
-                 const double* d_tab, double* d_density /*[nb][B][H] c128*/, void* stream);
+/* density[s][r][b][h] = x / (gh * blc): the reference's `density` from the equilibrated unknowns (also the
+ * single-ball shortcut _biem.py:648-691 with x = f).  x element (s, r, i) at d_x[s*sys_stride + i*elem_stride + r*rhs_stride]. */
+int biem_density(const biem_plan* plan, int nb, int B, int nrhs, const double* d_x, long long sys_stride, long long elem_stride,
+                 long long rhs_stride, const double* d_tab, double* d_density /*[nb][nrhs][B][H] c128*/, void* stream);
 
 /* ---- field evaluation (biem_u, _biem.py:822-977) ----
  * d_points[d][P] (or [d][P][nb] with BIEM_USCAT_POINTS_BATCHED); out[P][nb] or [P][nb][B] (per ball), complex128.
@@ -134,9 +135,10 @@ int biem_uscat(const biem_plan* plan, int nb, int B, int P, const double* d_k, c
                const double* d_points, int flags, double* d_out, void* d_work, size_t work_bytes, void* stream);
 
 /* ---- one call for the whole path: ball tables + fill (equilibrated) + LU + density, systems processed in
- *      chunks of `chunk` resident matrices (0 = choose).  d_g as in biem_rhs_project. ---- */
-size_t biem_solve_workspace_bytes(const biem_plan* plan, int nb, int B, int chunk);
-int biem_solve(const biem_plan* plan, int nb, int B, const double* d_k, const double* d_eta, const double* d_centers,
+ *      chunks of `chunk` resident matrices (0 = choose); every system is factored once for its nrhs right-hand sides.
+ *      d_g [nb][nrhs][B][Q] as in biem_rhs_project, d_density [nb][nrhs][B][H]. ---- */
+size_t biem_solve_workspace_bytes(const biem_plan* plan, int nb, int B, int nrhs, int chunk);
+int biem_solve(const biem_plan* plan, int nb, int B, int nrhs, const double* d_k, const double* d_eta, const double* d_centers,
                const double* d_radii, int geom_batched, const double* d_alpha, const double* d_beta, int ab_batched,
                const double* d_g, double* d_density, int* d_info, int chunk, void* d_work, size_t work_bytes, void* stream);
 

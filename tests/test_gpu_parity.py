@@ -379,3 +379,34 @@ def test_float32_inputs_and_per_ball_alpha_beta_batch(amd):
     uo, _ = O.plane_wave(1.0, [1.0, 0.0])
     ref = O.uscat(O.solve_biem("a", centers=cen, radii=rad, k=1.0, n_end=6, uin=uo), x)
     assert np.max(np.abs(u32.cpu().numpy() - ref) / np.abs(ref)) < 1e-5
+
+
+def test_factor_once_solve_many_incidences(amd, lib):
+    """Incidences on which the operator does not depend ride as right-hand sides of one factorisation:
+    k of shape (1, K), directions of shape (d, R, 1) -> density (R, K, B, H); equal to solving every (r, k) on its own."""
+    c = amd.create_from_branching_types("ba")
+    cen = np.array([[0.0, 1.6, 0.2], [0.3, -1.5, 0.0], [2.9, 0.1, -0.4]])
+    rad = np.array([1.0, 0.8, 0.6])
+    ks = np.array([[0.9, 2.1]])                                   # (1, K)
+    ang = np.array([0.0, 0.7, 2.0])
+    dirs = np.stack([np.cos(ang), np.sin(ang), 0.3 * np.ones(3)])[:, :, None]      # (d, R, 1)
+    uin, ugr = amd.plane_wave(k=_dev(ks), direction=_dev(dirs))
+    l, L = lib
+    L.check(l.biem_profile_begin())
+    calc = amd.biem(c, centers=_dev(cen)[None, None], radii=_dev(rad)[None, None], k=_dev(ks), n_end=7, alpha=1.0, beta=0.4,
+                    uin=uin, uin_grad=ugr)
+    ms, work, launches = (C.c_double * 9)(), (C.c_double * 9)(), (C.c_longlong * 9)()
+    L.check(l.biem_profile_end(ms, work, launches))
+    assert launches[1] == 1 and work[1] == 16.0 * 2 * (3 * 49) ** 2      # ONE fill of K = 2 systems, not R*K = 6
+    dens = calc.density
+    assert tuple(dens.shape) == (3, 2, 3, 49)
+    x = np.array([[5.0, 0.5, 0.2], [-3.0, 2.0, 1.0]])
+    u = calc.uscat(_dev(x.T)).cpu().numpy()                        # (P, R, K)
+    assert u.shape == (2, 3, 2)
+    for r in range(3):
+        for s in range(2):
+            uo, go = O.plane_wave(ks[0, s], dirs[:, r, 0])
+            res = O.solve_biem("ba", centers=cen, radii=rad, k=ks[0, s], n_end=7, alpha=1.0, beta=0.4, uin=uo, uin_grad=go)
+            ref = O.uscat(res, x)
+            assert np.max(np.abs(u[:, r, s] - ref) / np.abs(ref)) < 1e-10, (r, s)
+            assert np.max(np.abs(dens[r, s].cpu().numpy() - res.density)) < 1e-9 * np.abs(res.density).max()
