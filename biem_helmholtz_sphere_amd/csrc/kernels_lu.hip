@@ -329,6 +329,46 @@ __device__ inline void lds_wait() {
 //    chunk loop with a run-time stage offset;
 //  * per-lane 64-bit address arithmetic for 5 DMAs per chunk cost ~250 VALU instructions -> wave-uniform scalar bases plus
 //    per-lane 32-bit offsets that are constant for the whole kernel.
+__device__ int g_cu_ticket[8 * 256];
+#ifdef BIEM_EXP_NT
+#define BIEM_C_NT " nt"
+#else
+#define BIEM_C_NT ""
+#endif
+#ifndef BIEM_PRIO_VARIANT
+#define BIEM_PRIO_VARIANT 0
+#endif
+#if BIEM_PRIO_VARIANT == 0
+#define BIEM_PRIO_M() __builtin_amdgcn_s_setprio(1)
+#define BIEM_PRIO_O() __builtin_amdgcn_s_setprio(3)
+#elif BIEM_PRIO_VARIANT == 1
+#define BIEM_PRIO_M() __builtin_amdgcn_s_setprio(3)
+#define BIEM_PRIO_O() __builtin_amdgcn_s_setprio(0)
+#elif BIEM_PRIO_VARIANT == 2
+#define BIEM_PRIO_M() { if (hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
+#define BIEM_PRIO_O() __builtin_amdgcn_s_setprio(3)
+#elif BIEM_PRIO_VARIANT == 3
+#define BIEM_PRIO_M() { if (hi) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
+#define BIEM_PRIO_O() __builtin_amdgcn_s_setprio(1)
+#else
+#define BIEM_PRIO_M()
+#define BIEM_PRIO_O()
+#endif
+#ifdef BIEM_GEMM_TRACE
+// diagnostic build only (tools/gemm_trace.cpp): wave 0 of the first 4 workgroups stamps (all 4 waves) s_memtime at 7 points of each of its
+// first 64 chunks into LDS and dumps them at exit (no VM traffic inside the loop, the hand-counted vmcnt waits stay valid)
+__device__ unsigned long long g_gemm_trace[16][64][8];
+#ifdef BIEM_TR_STAMPS
+#define BIEM_TR(i) { if (lane == 0 && tr_n < 64) s_tr[(wave * 64 + tr_n) * 8 + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define BIEM_TR_NEXT() { ++tr_n; }
+#else
+#define BIEM_TR(i)
+#define BIEM_TR_NEXT()
+#endif
+#else
+#define BIEM_TR(i)
+#define BIEM_TR_NEXT()
+#endif
 template <int KD>
 __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, long long lda, long long sys_stride,
                                                          const cplx* __restrict__ Pw, long long ldp, long long p_stride,
@@ -336,7 +376,13 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
   const int n_pad = tg.row_end, n_cols = tg.col_end;
   constexpr int NCH = KD / KC;               // 8 or 16 K-chunks per tile
   constexpr int UPC = 16 / NCH;              // C units (one complex per lane) per chunk: 2 or 1
+#if defined(BIEM_EXP) && BIEM_EXP == 6        // experiment: no C-slice DMA in the fused (interior, K = 128) path
+  constexpr int NDMA = 4;
+#elif defined(BIEM_EXP) && BIEM_EXP == 7      // experiment: only the C-slice DMA
+  constexpr int NDMA = 1;
+#else
   constexpr int NDMA = 4 + UPC;              // LDS-DMA instructions per wave per chunk
+#endif
   constexpr int AST = 68;                    // A row stride in LDS: +4 elements (64 B) so the broadcast A-fragment reads of
                                              // two k-rows in one ds_read_b128 lane group hit different banks
   constexpr int BOF = KC * AST;              // B block offset inside a stage
@@ -391,7 +437,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
   };
   producer_tile();
   // issue the DMA group of the producer's current chunk into stage st (exactly NDMA instructions, all lanes active), advance
-  auto issue = [&](int st) {
+  auto issue_dma = [&](int st) {
     cplx* S = ring + st * STG;
     if (p_interior) {
       __builtin_amdgcn_global_load_lds((glb_ptr_t)(pA + offA0), (lds_ptr_t)(S + wave * AST), 16, 0, 0);
@@ -427,6 +473,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
                                          (lds_ptr_t)(S + COF + i * 256 + wave * 64), 16, 0, 0);
       }
     }
+  };
+  auto advance = [&]() {
     pA += strideA; pB += strideB;
     if (++p_ch == NCH) {                                   // producer moves on to the next tile of this workgroup
       int tn = next_tile();
@@ -443,6 +491,24 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
 #pragma unroll
       for (int g = 0; g < 4; ++g) { N1[a][b][g] = 0.0; P2[a][b][g] = 0.0; N3[a][b][g] = 0.0; }
 
+  // The two workgroups resident on a CU put one wave each on every SIMD.  With equal priority their MFMA blocks share the
+  // matrix pipe fairly, finish together and then both sit in the barrier / DMA / fragment-read phase together (lock step:
+  // the pipe idles).  Unequal MFMA-block priorities serialise the two blocks instead, so one wave's non-MFMA phase always
+  // runs under the partner's MFMA block.  The wave slot parity of wave 0 (HW_ID[3:0]) tells the two workgroups apart.
+#ifdef BIEM_GEMM_TRACE
+  __shared__ unsigned long long s_tr[4 * 64 * 8];
+  int tr_n = 0;
+  for (int i = tid; i < 4 * 64 * 8; i += 256) s_tr[i] = 0;
+#endif
+  __shared__ int s_hi;
+  if (tid == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4);     // HW_ID: cu_id[11:8] sh_id[12] se_id[15:13]
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);   // XCC_ID[3:0]
+    s_hi = atomicAdd(&g_cu_ticket[(xcc & 7) * 256 + ((hw >> 8) & 255)], 1) & 1;
+  }
+  __syncthreads();
+  const bool hi = __builtin_amdgcn_readfirstlane(s_hi) != 0;
+  auto issue = [&](int st) { issue_dma(st); advance(); };
   issue(0);
   issue(1);
   int st = 0;                 // stage of the chunk about to be multiplied
@@ -450,6 +516,13 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
   // per-lane LDS offsets of the fragments inside a stage (elements)
   const int fbo = BOF + l4 * 64 + wn * 32 + l15;          // + k4*4*64 + n*16
   const int fao = l4 * AST + wm * 32 + l3;                // + k4*4*AST + tm*16 + 4g
+  // A VALU instruction issued while the SIMD partner (the other workgroup's wave) streams MFMAs costs ~28 cycles even at
+  // priority 3 (tools/mfma_valu_mix: 8 alone, 101 at equal priority; SALU and LDS instructions are unaffected).  So the
+  // phase between two MFMA blocks holds no VALU work at all: the fragment addresses of the NEXT chunk, the 3M operand sums
+  // and the C-slice additions are all issued inside this wave's own MFMA block, in the shadow of its MFMAs.
+  typedef const __attribute__((address_space(3))) cplx* lds_cptr_t;
+  unsigned aA = (unsigned)(size_t)(lds_cptr_t)(ring + fao), aB = (unsigned)(size_t)(lds_cptr_t)(ring + fbo),
+           aC = (unsigned)(size_t)(lds_cptr_t)(ring + COF + tid);                      // stage 0
   // the producer is exactly one tile ahead whenever the consumer finishes a tile (it switches at the consumer's chunk
   // NCH-3 and not again before chunk NCH-3 of the next tile): its current coordinates are the consumer's next tile
   for (;;) {
@@ -457,6 +530,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
     for (int c = 0; c < NCH; ++c) {
       // retire this chunk's DMA group (mine), then meet the other waves: their groups have landed too and nobody still
       // reads the stage the next group is about to overwrite
+      BIEM_TR(0)
       if (__builtin_expect(stores_pending == 0 && p_valid, 1)) {
         wait_vmcnt<NDMA>();
       } else if (!p_valid) {
@@ -468,20 +542,65 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
       } else {
         wait_vmcnt<NDMA>();
       }
+      BIEM_TR(1)
+#ifndef BIEM_ABL_NOBARRIER
       __builtin_amdgcn_s_barrier();
+#endif
       __builtin_amdgcn_sched_barrier(0);
+      BIEM_TR(2)
       const int st2 = st >= 1 ? st - 1 : 2;            // (st + 2) % 3
-      if (p_valid) issue(st2);
+      // interior chunks of the K = 128 kernel put their DMA group between the fragment reads and the lgkmcnt wait (below):
+      // the VMEM issue (~100 cycles per instruction with 8 waves' groups in flight) then runs under the LDS latency
+#if defined(BIEM_EXP) && BIEM_EXP == 2     // experiment: no DMA at all (compute-only period)
+      const bool fused = false;
+      if (p_valid) advance();
+#else
+      const bool fused = UPC == 1 && p_valid && p_interior;
+      if (p_valid && !fused) issue(st2);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      BIEM_TR(3)
       const cplx* S = ring + st * STG;
       // fragments of both k4-steps and the C units of this chunk: 20 + UPC ds_read_b128 and their lgkmcnt wait in ONE asm
       // statement - hipcc may copy an asm output right after the statement, i.e. before a separate wait (that was the
       // cause of percent-level errors in an earlier build); byte offsets: k4*4352 + tm*256 + g*64 (A), k4*4096 + n*256 (B)
       cplx fb[2][2], fa[2][2][4], cv[UPC];
       {
-        const unsigned aA = (unsigned)(size_t)(const __attribute__((address_space(3))) cplx*)(S + fao);
-        const unsigned aB = (unsigned)(size_t)(const __attribute__((address_space(3))) cplx*)(S + fbo);
-        const unsigned aC = (unsigned)(size_t)(const __attribute__((address_space(3))) cplx*)(S + COF + tid);
-        if constexpr (UPC == 1) {
+        if (UPC == 1 && fused) {
+          typedef __attribute__((address_space(3))) cplx* lds_cplx_t;
+          cplx* S2 = ring + st2 * STG;
+          const unsigned mA = (unsigned)(size_t)(lds_cplx_t)(S2 + wave * AST), mB = (unsigned)(size_t)(lds_cplx_t)(S2 + BOF + wave * 64);
+          const long long dC = ((long long)((p_ch >> 3) * 16 + 4 * (p_ch & 3)) * lda + ((p_ch >> 2) & 1) * 16) * (long long)sizeof(cplx);
+          const char* pCc = pC + dC;
+          asm volatile(
+#ifndef BIEM_ABL_NOLDS
+              "ds_read_b128 %[b0], %[aB]\n\tds_read_b128 %[b1], %[aB] offset:256\n\tds_read_b128 %[b2], %[aB] offset:4096\n\tds_read_b128 %[b3], %[aB] offset:4352\n\t"
+              "ds_read_b128 %[a0], %[aA]\n\tds_read_b128 %[a1], %[aA] offset:64\n\tds_read_b128 %[a2], %[aA] offset:128\n\tds_read_b128 %[a3], %[aA] offset:192\n\t"
+              "ds_read_b128 %[a4], %[aA] offset:256\n\tds_read_b128 %[a5], %[aA] offset:320\n\tds_read_b128 %[a6], %[aA] offset:384\n\tds_read_b128 %[a7], %[aA] offset:448\n\t"
+              "ds_read_b128 %[a8], %[aA] offset:4352\n\tds_read_b128 %[a9], %[aA] offset:4416\n\tds_read_b128 %[a10], %[aA] offset:4480\n\tds_read_b128 %[a11], %[aA] offset:4544\n\t"
+              "ds_read_b128 %[a12], %[aA] offset:4608\n\tds_read_b128 %[a13], %[aA] offset:4672\n\tds_read_b128 %[a14], %[aA] offset:4736\n\tds_read_b128 %[a15], %[aA] offset:4800\n\t"
+              "ds_read_b128 %[c0], %[aC]\n\t"
+#endif
+#if !(defined(BIEM_EXP) && BIEM_EXP == 7)
+              "s_mov_b32 m0, %[mA]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oA0], %[pA]\n\t"
+              "s_add_u32 m0, %[mA], 4352\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oA1], %[pA]\n\t"
+              "s_mov_b32 m0, %[mB]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oB0], %[pB]\n\t"
+              "s_add_u32 m0, %[mB], 4096\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oB1], %[pB]\n\t"
+#endif
+#if !(defined(BIEM_EXP) && BIEM_EXP == 6)
+              "s_add_u32 m0, %[mB], 8192\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oC], %[pC]" BIEM_C_NT "\n\t"
+#endif
+              "s_waitcnt lgkmcnt(0)"
+              : [a0] "=&v"(fa[0][0][0]), [a1] "=&v"(fa[0][0][1]), [a2] "=&v"(fa[0][0][2]), [a3] "=&v"(fa[0][0][3]), [a4] "=&v"(fa[0][1][0]),
+                [a5] "=&v"(fa[0][1][1]), [a6] "=&v"(fa[0][1][2]), [a7] "=&v"(fa[0][1][3]), [a8] "=&v"(fa[1][0][0]), [a9] "=&v"(fa[1][0][1]),
+                [a10] "=&v"(fa[1][0][2]), [a11] "=&v"(fa[1][0][3]), [a12] "=&v"(fa[1][1][0]), [a13] "=&v"(fa[1][1][1]), [a14] "=&v"(fa[1][1][2]),
+                [a15] "=&v"(fa[1][1][3]), [b0] "=&v"(fb[0][0]), [b1] "=&v"(fb[0][1]), [b2] "=&v"(fb[1][0]), [b3] "=&v"(fb[1][1]), [c0] "=&v"(cv[0])
+              : [aA] "v"(aA), [aB] "v"(aB), [aC] "v"(aC), [mA] "s"(mA), [mB] "s"(mB), [oA0] "v"(offA0), [oA1] "v"(offA1), [oB0] "v"(offB0),
+                [oB1] "v"(offB1), [oC] "v"(offC), [pA] "s"(pA), [pB] "s"(pB), [pC] "s"(pCc)
+              : "memory", "m0", "scc");
+          __builtin_amdgcn_sched_barrier(0);
+          advance();
+        } else if constexpr (UPC == 1) {
           asm volatile(
               "ds_read_b128 %16, %22\n\tds_read_b128 %17, %22 offset:256\n\tds_read_b128 %18, %22 offset:4096\n\tds_read_b128 %19, %22 offset:4352\n\t"
               "ds_read_b128 %0, %21\n\tds_read_b128 %1, %21 offset:64\n\tds_read_b128 %2, %21 offset:128\n\tds_read_b128 %3, %21 offset:192\n\t"
@@ -514,30 +633,81 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      // operand sums of the 3M form for both k4-steps, then one uninterrupted block of 96 MFMAs
-      double fbs[2][2], fas[2][2][4];
+      BIEM_TR(4)
+      // the MFMA block runs at low priority, everything else at high (the partner's SALU / LDS / VMEM phase slips between
+      // this wave's MFMAs).  All of this chunk's VALU work sits inside the block, one or two instructions after each MFMA of
+      // the groups that do not need it yet: next chunk's fragment addresses, the 3M operand sums right before the group that
+      // multiplies them, the C-slice additions at the end.
+#ifndef BIEM_SUMS_INSIDE
+      double fbs_o[2][2], fas_o[2][2][4];
 #pragma unroll
       for (int k4 = 0; k4 < 2; ++k4) {
 #pragma unroll
-        for (int n = 0; n < 2; ++n) fbs[k4][n] = fb[k4][n].x + fb[k4][n].y;
+#ifdef BIEM_ABL_NOSUMS
+        for (int n = 0; n < 2; ++n) fbs_o[k4][n] = fb[k4][n].x;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) fas[k4][tm][g] = fa[k4][tm][g].x + fa[k4][tm][g].y;
+          for (int g = 0; g < 4; ++g) fas_o[k4][tm][g] = fa[k4][tm][g].x;
+#else
+        for (int n = 0; n < 2; ++n) fbs_o[k4][n] = fb[k4][n].x + fb[k4][n].y;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) fas_o[k4][tm][g] = fa[k4][tm][g].x + fa[k4][tm][g].y;
+#endif
       }
+#endif
+#if !defined(BIEM_CADD_INSIDE) && !defined(BIEM_ABL_NOCADD)
+#pragma unroll
+      for (int i = 0; i < UPC; ++i) {
+        (&N1[0][0][0])[c * UPC + i] += cv[i].x;
+        (&N3[0][0][0])[c * UPC + i] += cv[i].x + cv[i].y;
+      }
+#endif
       mfma_fence();
-      // the MFMA block runs at low priority, everything else at high: the SIMD partner's barrier / DMA / fragment-read
-      // phase then slips between this wave's MFMAs (which need 4 of every 16 issue cycles): +2-3 % measured.  Delaying one
-      // of the two resident workgroups by half a chunk, or issuing the DMA group between the two k4 halves, changed nothing.
-      __builtin_amdgcn_s_setprio(0);
+      BIEM_PRIO_M();
+      mfma_fence();
+      BIEM_TR(5)
+      {
+        const int stn = st == 2 ? 0 : st + 1;
+        const unsigned sbase = (unsigned)(size_t)(lds_cptr_t)(ring + stn * STG);     // wave-uniform
+        aA = sbase + (unsigned)(fao * (int)sizeof(cplx));
+        aB = sbase + (unsigned)(fbo * (int)sizeof(cplx));
+        aC = sbase + (unsigned)((COF + tid) * (int)sizeof(cplx));
+      }
+#if defined(BIEM_EXP) && BIEM_EXP == 1     // experiment: no MFMAs (data-movement-only period)
 #pragma unroll
       for (int k4 = 0; k4 < 2; ++k4) {
+        asm volatile("" ::"v"(fb[k4][0].x), "v"(fb[k4][0].y), "v"(fb[k4][1].x), "v"(fb[k4][1].y));
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(fa[k4][tm][g].x), "v"(fa[k4][tm][g].y));
+      }
+#else
+#pragma unroll
+      for (int k4 = 0; k4 < 2; ++k4) {
+        double fbs[2];
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
+          double fas[4];
 #pragma unroll
           for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int g = 0; g < 4; ++g) mfma_acc_neg(N1[tm][n][g], fa[k4][tm][g].x, fb[k4][n].x);
+#ifndef BIEM_SUMS_INSIDE
+          if (tm == 0) { fbs[0] = fbs_o[k4][0]; fbs[1] = fbs_o[k4][1]; }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) fas[g] = fas_o[k4][tm][g];
+#else
+          if (tm == 0) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n) fbs[n] = fb[k4][n].x + fb[k4][n].y;
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) fas[g] = fa[k4][tm][g].x + fa[k4][tm][g].y;
+#endif
 #pragma unroll
           for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -545,27 +715,28 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
 #pragma unroll
           for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) mfma_acc_neg(N3[tm][n][g], fas[k4][tm][g], fbs[k4][n]);
+            for (int g = 0; g < 4; ++g) mfma_acc_neg(N3[tm][n][g], fas[g], fbs[n]);
         }
       }
-      mfma_fence();
-      __builtin_amdgcn_s_setprio(3);
-      // this chunk's C units (u = c*UPC + i -> sub-tile (u>>3, (u>>2)&1), register u&3) join their accumulators
-#define BIEM_CADD3(U, V) { N1[(U) >> 3][((U) >> 2) & 1][(U) & 3] += (V).x; N3[(U) >> 3][((U) >> 2) & 1][(U) & 3] += (V).x + (V).y; }
+#endif
+      // this chunk's C units (u = c*UPC + i -> sub-tile (u>>3, (u>>2)&1), register u&3) join their accumulators.  Which
+      // accumulator that is depends on c: a switch over c made hipcc merge all 32 accumulators through v_mov_b64 copies
+      // behind the MFMA block (~1300 stalled cycles per chunk, found with tools/gemm_trace), an fma(value, sel_u, acc_u) over
+      // all units cost 32 FP64 VALU instructions that compete with the MFMAs for the FP64 pipe.  A dynamically indexed
+      // register array compiles to s_set_gpr_idx + v_mov (indirect VGPR addressing): 3 FP64 adds per unit.
+#ifdef BIEM_CADD_INSIDE
 #pragma unroll
       for (int i = 0; i < UPC; ++i) {
-        switch (c * UPC + i) {   // wave-uniform; accumulator indices must be compile-time constants
-          case 0: BIEM_CADD3(0, cv[i]) break;   case 1: BIEM_CADD3(1, cv[i]) break;
-          case 2: BIEM_CADD3(2, cv[i]) break;   case 3: BIEM_CADD3(3, cv[i]) break;
-          case 4: BIEM_CADD3(4, cv[i]) break;   case 5: BIEM_CADD3(5, cv[i]) break;
-          case 6: BIEM_CADD3(6, cv[i]) break;   case 7: BIEM_CADD3(7, cv[i]) break;
-          case 8: BIEM_CADD3(8, cv[i]) break;   case 9: BIEM_CADD3(9, cv[i]) break;
-          case 10: BIEM_CADD3(10, cv[i]) break; case 11: BIEM_CADD3(11, cv[i]) break;
-          case 12: BIEM_CADD3(12, cv[i]) break; case 13: BIEM_CADD3(13, cv[i]) break;
-          case 14: BIEM_CADD3(14, cv[i]) break; default: BIEM_CADD3(15, cv[i]) break;
-        }
+        (&N1[0][0][0])[c * UPC + i] += cv[i].x;
+        (&N3[0][0][0])[c * UPC + i] += cv[i].x + cv[i].y;
       }
-#undef BIEM_CADD3
+#endif
+      mfma_fence();
+      BIEM_PRIO_O();
+      BIEM_TR(6)
+      __builtin_amdgcn_sched_barrier(0);
+      BIEM_TR(7)
+      BIEM_TR_NEXT()
       st = st == 2 ? 0 : st + 1;
       if (c == 1) stores_pending = 0;
     }
@@ -592,6 +763,14 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
     stores_pending = full ? 1 : 2;
     cs = p_s; cty = p_ty; ctx = p_tx;
   }
+#ifdef BIEM_GEMM_TRACE
+  __syncthreads();
+  if (blockIdx.x < 4) {     // 4 workgroups x 4 waves
+    if (lane == 0) s_tr[wave * 512 + 7] = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4);     // HW_ID[15:0]
+    __syncthreads();
+    for (int i = tid; i < 4 * 64 * 8; i += 256) g_gemm_trace[blockIdx.x * 4 + (i >> 9)][(i >> 3) & 63][i & 7] = s_tr[i];
+  }
+#endif
 }
 
 // C[row_begin:row_end, col_begin:col_end] -= P[0:kd]^T (rows of the region) * M[brow:brow+kd, cols of the region]
@@ -604,7 +783,11 @@ static void launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, l
   tg.ty_n = (rrows + BM3 - 1) / BM3; tg.tx_n = (rcols + BN3 - 1) / BN3;
   tg.per_sys = tg.ty_n * tg.tx_n; tg.full_bands = tg.ty_n / 8; tg.ntiles = tg.per_sys * nb;
   tg.row_begin = row_begin; tg.row_end = row_end; tg.col_begin = col_begin; tg.col_end = col_end; tg.brow = brow;
+#ifdef BIEM_GRID_CAP
+  const int cap = BIEM_GRID_CAP;               // experiment
+#else
   const int cap = 512;                         // persistent grid: 2 workgroups per CU
+#endif
   int want = (tg.ntiles + 7) / 8 * 8;          // one workgroup per tile up to the cap, multiple of 8
   int grid = want < cap ? want : cap;
   ProfScope ps(prof_class, st, prof_work >= 0.0 ? prof_work : 8.0 * (double)nb * rrows * (double)rcols * kd);
@@ -817,5 +1000,33 @@ int bench_mfma_f64(int iters, double* tflops, hipStream_t st) {
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
   return BIEM_OK;
 }
+
+#ifdef BIEM_GEMM_TRACE
+__global__ void k_trace_fill(double* p, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = 1e-3 * (double)((i * 2654435761ull >> 7) & 1023) / 1024.0 - 5e-4;
+}
+// one trailing update of an (n x n, K = kd) region of nb systems on synthetic data; returns the stamps and the launch time
+extern "C" int biem_debug_gemm(int nb, int n, int kd, int reps, unsigned long long* trace_out, float* ms_out) {
+  const long long lda = n + 8, ldp = n + 128;   // the panel workspace is indexed by absolute row
+  cplx *A = nullptr, *P = nullptr;
+  const size_t na = (size_t)nb * (n + 128) * lda, np = (size_t)nb * 128 * ldp;
+  if (hipMalloc((void**)&A, na * sizeof(cplx)) != hipSuccess) return 1;
+  if (hipMalloc((void**)&P, np * sizeof(cplx)) != hipSuccess) return 1;
+  hipLaunchKernelGGL(k_trace_fill, dim3(2048), dim3(256), 0, 0, (double*)A, na * 2);
+  hipLaunchKernelGGL(k_trace_fill, dim3(2048), dim3(256), 0, 0, (double*)P, np * 2);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  launch_gemm_stream(0, nb, A, lda, (long long)(n + 128) * lda, P, ldp, 128 * ldp, 128, 128 + n, 0, n, 0, kd);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  for (int r = 0; r < reps; ++r)
+    launch_gemm_stream(0, nb, A, lda, (long long)(n + 128) * lda, P, ldp, 128 * ldp, 128, 128 + n, 0, n, 0, kd);
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1); *ms_out = ms / reps;
+  hipMemcpyFromSymbol(trace_out, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * 16 * 64 * 8);
+  hipFree(A); hipFree(P);
+  return 0;
+}
+#endif
 
 }  // namespace biem
