@@ -329,31 +329,8 @@ __device__ inline void lds_wait() {
 //    chunk loop with a run-time stage offset;
 //  * per-lane 64-bit address arithmetic for 5 DMAs per chunk cost ~250 VALU instructions -> wave-uniform scalar bases plus
 //    per-lane 32-bit offsets that are constant for the whole kernel.
-__device__ int g_cu_ticket[8 * 256];
-#ifdef BIEM_EXP_NT
-#define BIEM_C_NT " nt"
-#else
-#define BIEM_C_NT ""
-#endif
-#ifndef BIEM_PRIO_VARIANT
-#define BIEM_PRIO_VARIANT 0
-#endif
-#if BIEM_PRIO_VARIANT == 0
 #define BIEM_PRIO_M() __builtin_amdgcn_s_setprio(1)
 #define BIEM_PRIO_O() __builtin_amdgcn_s_setprio(3)
-#elif BIEM_PRIO_VARIANT == 1
-#define BIEM_PRIO_M() __builtin_amdgcn_s_setprio(3)
-#define BIEM_PRIO_O() __builtin_amdgcn_s_setprio(0)
-#elif BIEM_PRIO_VARIANT == 2
-#define BIEM_PRIO_M() { if (hi) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
-#define BIEM_PRIO_O() __builtin_amdgcn_s_setprio(3)
-#elif BIEM_PRIO_VARIANT == 3
-#define BIEM_PRIO_M() { if (hi) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2); }
-#define BIEM_PRIO_O() __builtin_amdgcn_s_setprio(1)
-#else
-#define BIEM_PRIO_M()
-#define BIEM_PRIO_O()
-#endif
 #ifdef BIEM_GEMM_TRACE
 // diagnostic build only (tools/gemm_trace.cpp): wave 0 of the first 4 workgroups stamps (all 4 waves) s_memtime at 7 points of each of its
 // first 64 chunks into LDS and dumps them at exit (no VM traffic inside the loop, the hand-counted vmcnt waits stay valid)
@@ -376,9 +353,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
   const int n_pad = tg.row_end, n_cols = tg.col_end;
   constexpr int NCH = KD / KC;               // 8 or 16 K-chunks per tile
   constexpr int UPC = 16 / NCH;              // C units (one complex per lane) per chunk: 2 or 1
-#if defined(BIEM_EXP) && BIEM_EXP == 6        // experiment: no C-slice DMA in the fused (interior, K = 128) path
+#if defined(BIEM_ABL_NOCDMA)                  // timing ablation: no C-slice DMA in the fused (interior, K = 128) path
   constexpr int NDMA = 4;
-#elif defined(BIEM_EXP) && BIEM_EXP == 7      // experiment: only the C-slice DMA
+#elif defined(BIEM_ABL_ONLYCDMA)              // timing ablation: only the C-slice DMA
   constexpr int NDMA = 1;
 #else
   constexpr int NDMA = 4 + UPC;              // LDS-DMA instructions per wave per chunk
@@ -491,23 +468,12 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
 #pragma unroll
       for (int g = 0; g < 4; ++g) { N1[a][b][g] = 0.0; P2[a][b][g] = 0.0; N3[a][b][g] = 0.0; }
 
-  // The two workgroups resident on a CU put one wave each on every SIMD.  With equal priority their MFMA blocks share the
-  // matrix pipe fairly, finish together and then both sit in the barrier / DMA / fragment-read phase together (lock step:
-  // the pipe idles).  Unequal MFMA-block priorities serialise the two blocks instead, so one wave's non-MFMA phase always
-  // runs under the partner's MFMA block.  The wave slot parity of wave 0 (HW_ID[3:0]) tells the two workgroups apart.
-#ifdef BIEM_GEMM_TRACE
+#ifdef BIEM_TR_STAMPS
   __shared__ unsigned long long s_tr[4 * 64 * 8];
   int tr_n = 0;
   for (int i = tid; i < 4 * 64 * 8; i += 256) s_tr[i] = 0;
-#endif
-  __shared__ int s_hi;
-  if (tid == 0) {
-    const unsigned hw = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4);     // HW_ID: cu_id[11:8] sh_id[12] se_id[15:13]
-    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);   // XCC_ID[3:0]
-    s_hi = atomicAdd(&g_cu_ticket[(xcc & 7) * 256 + ((hw >> 8) & 255)], 1) & 1;
-  }
   __syncthreads();
-  const bool hi = __builtin_amdgcn_readfirstlane(s_hi) != 0;
+#endif
   auto issue = [&](int st) { issue_dma(st); advance(); };
   issue(0);
   issue(1);
@@ -551,7 +517,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
       const int st2 = st >= 1 ? st - 1 : 2;            // (st + 2) % 3
       // interior chunks of the K = 128 kernel put their DMA group between the fragment reads and the lgkmcnt wait (below):
       // the VMEM issue (~100 cycles per instruction with 8 waves' groups in flight) then runs under the LDS latency
-#if defined(BIEM_EXP) && BIEM_EXP == 2     // experiment: no DMA at all (compute-only period)
+#ifdef BIEM_ABL_NODMA      // timing ablation: no DMA at all (compute-only period)
       const bool fused = false;
       if (p_valid) advance();
 #else
@@ -581,14 +547,14 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
               "ds_read_b128 %[a12], %[aA] offset:4608\n\tds_read_b128 %[a13], %[aA] offset:4672\n\tds_read_b128 %[a14], %[aA] offset:4736\n\tds_read_b128 %[a15], %[aA] offset:4800\n\t"
               "ds_read_b128 %[c0], %[aC]\n\t"
 #endif
-#if !(defined(BIEM_EXP) && BIEM_EXP == 7)
+#ifndef BIEM_ABL_ONLYCDMA
               "s_mov_b32 m0, %[mA]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oA0], %[pA]\n\t"
               "s_add_u32 m0, %[mA], 4352\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oA1], %[pA]\n\t"
               "s_mov_b32 m0, %[mB]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oB0], %[pB]\n\t"
               "s_add_u32 m0, %[mB], 4096\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oB1], %[pB]\n\t"
 #endif
-#if !(defined(BIEM_EXP) && BIEM_EXP == 6)
-              "s_add_u32 m0, %[mB], 8192\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oC], %[pC]" BIEM_C_NT "\n\t"
+#ifndef BIEM_ABL_NOCDMA
+              "s_add_u32 m0, %[mB], 8192\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oC], %[pC]\n\t"
 #endif
               "s_waitcnt lgkmcnt(0)"
               : [a0] "=&v"(fa[0][0][0]), [a1] "=&v"(fa[0][0][1]), [a2] "=&v"(fa[0][0][2]), [a3] "=&v"(fa[0][0][3]), [a4] "=&v"(fa[0][1][0]),
@@ -634,37 +600,42 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
         __builtin_amdgcn_sched_barrier(0);
       }
       BIEM_TR(4)
-      // the MFMA block runs at low priority, everything else at high (the partner's SALU / LDS / VMEM phase slips between
-      // this wave's MFMAs).  All of this chunk's VALU work sits inside the block, one or two instructions after each MFMA of
-      // the groups that do not need it yet: next chunk's fragment addresses, the 3M operand sums right before the group that
-      // multiplies them, the C-slice additions at the end.
-#ifndef BIEM_SUMS_INSIDE
-      double fbs_o[2][2], fas_o[2][2][4];
+      // 3M operand sums and the C-slice additions BEFORE the MFMA block (measured: issued inside the block, in the shadow of
+      // this wave's own MFMAs, the FP64 adds cost more - they share the FP64 pipe with the MFMAs and the C additions then
+      // wait for accumulators in flight: 57.6 vs 63.1 TFLOP/s; only the integer address work below is free in there).
+      double fbs[2][2], fas[2][2][4];
 #pragma unroll
       for (int k4 = 0; k4 < 2; ++k4) {
-#pragma unroll
 #ifdef BIEM_ABL_NOSUMS
-        for (int n = 0; n < 2; ++n) fbs_o[k4][n] = fb[k4][n].x;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) fbs[k4][n] = fb[k4][n].x;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) fas_o[k4][tm][g] = fa[k4][tm][g].x;
+          for (int g = 0; g < 4; ++g) fas[k4][tm][g] = fa[k4][tm][g].x;
 #else
-        for (int n = 0; n < 2; ++n) fbs_o[k4][n] = fb[k4][n].x + fb[k4][n].y;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) fbs[k4][n] = fb[k4][n].x + fb[k4][n].y;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) fas_o[k4][tm][g] = fa[k4][tm][g].x + fa[k4][tm][g].y;
+          for (int g = 0; g < 4; ++g) fas[k4][tm][g] = fa[k4][tm][g].x + fa[k4][tm][g].y;
 #endif
       }
-#endif
-#if !defined(BIEM_CADD_INSIDE) && !defined(BIEM_ABL_NOCADD)
+      // this chunk's C units (u = c*UPC + i -> sub-tile (u>>3, (u>>2)&1), register u&3) join their accumulators.  Which
+      // accumulator that is depends on c: a switch over c made hipcc merge all 32 accumulators through v_mov_b64 copies
+      // behind the MFMA block (~1300 stalled cycles per chunk, found with tools/gemm_trace), an fma(value, sel_u, acc_u) over
+      // all units cost 32 FP64 VALU instructions that compete with the MFMAs for the FP64 pipe.  A dynamically indexed
+      // register array compiles to s_set_gpr_idx + v_mov (indirect VGPR addressing): 3 FP64 adds per unit.
+#ifndef BIEM_ABL_NOCADD
 #pragma unroll
       for (int i = 0; i < UPC; ++i) {
         (&N1[0][0][0])[c * UPC + i] += cv[i].x;
         (&N3[0][0][0])[c * UPC + i] += cv[i].x + cv[i].y;
       }
 #endif
+      // the MFMA block runs at low priority, everything else at high (the partner's SALU / LDS / VMEM phase slips between
+      // this wave's MFMAs); the next chunk's fragment addresses are computed in its shadow
       mfma_fence();
       BIEM_PRIO_M();
       mfma_fence();
@@ -676,38 +647,24 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
         aB = sbase + (unsigned)(fbo * (int)sizeof(cplx));
         aC = sbase + (unsigned)((COF + tid) * (int)sizeof(cplx));
       }
-#if defined(BIEM_EXP) && BIEM_EXP == 1     // experiment: no MFMAs (data-movement-only period)
+#ifdef BIEM_ABL_NOMFMA     // timing ablation: data movement only
 #pragma unroll
       for (int k4 = 0; k4 < 2; ++k4) {
-        asm volatile("" ::"v"(fb[k4][0].x), "v"(fb[k4][0].y), "v"(fb[k4][1].x), "v"(fb[k4][1].y));
+        asm volatile("" ::"v"(fb[k4][0].x), "v"(fb[k4][0].y), "v"(fb[k4][1].x), "v"(fb[k4][1].y), "v"(fbs[k4][0]), "v"(fbs[k4][1]));
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(fa[k4][tm][g].x), "v"(fa[k4][tm][g].y));
+          for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(fa[k4][tm][g].x), "v"(fa[k4][tm][g].y), "v"(fas[k4][tm][g]));
       }
 #else
 #pragma unroll
       for (int k4 = 0; k4 < 2; ++k4) {
-        double fbs[2];
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
-          double fas[4];
 #pragma unroll
           for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int g = 0; g < 4; ++g) mfma_acc_neg(N1[tm][n][g], fa[k4][tm][g].x, fb[k4][n].x);
-#ifndef BIEM_SUMS_INSIDE
-          if (tm == 0) { fbs[0] = fbs_o[k4][0]; fbs[1] = fbs_o[k4][1]; }
-#pragma unroll
-          for (int g = 0; g < 4; ++g) fas[g] = fas_o[k4][tm][g];
-#else
-          if (tm == 0) {
-#pragma unroll
-            for (int n = 0; n < 2; ++n) fbs[n] = fb[k4][n].x + fb[k4][n].y;
-          }
-#pragma unroll
-          for (int g = 0; g < 4; ++g) fas[g] = fa[k4][tm][g].x + fa[k4][tm][g].y;
-#endif
 #pragma unroll
           for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -715,20 +672,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
 #pragma unroll
           for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) mfma_acc_neg(N3[tm][n][g], fas[g], fbs[n]);
+            for (int g = 0; g < 4; ++g) mfma_acc_neg(N3[tm][n][g], fas[k4][tm][g], fbs[k4][n]);
         }
-      }
-#endif
-      // this chunk's C units (u = c*UPC + i -> sub-tile (u>>3, (u>>2)&1), register u&3) join their accumulators.  Which
-      // accumulator that is depends on c: a switch over c made hipcc merge all 32 accumulators through v_mov_b64 copies
-      // behind the MFMA block (~1300 stalled cycles per chunk, found with tools/gemm_trace), an fma(value, sel_u, acc_u) over
-      // all units cost 32 FP64 VALU instructions that compete with the MFMAs for the FP64 pipe.  A dynamically indexed
-      // register array compiles to s_set_gpr_idx + v_mov (indirect VGPR addressing): 3 FP64 adds per unit.
-#ifdef BIEM_CADD_INSIDE
-#pragma unroll
-      for (int i = 0; i < UPC; ++i) {
-        (&N1[0][0][0])[c * UPC + i] += cv[i].x;
-        (&N3[0][0][0])[c * UPC + i] += cv[i].x + cv[i].y;
       }
 #endif
       mfma_fence();
@@ -740,22 +685,45 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
       st = st == 2 ? 0 : st + 1;
       if (c == 1) stores_pending = 0;
     }
-    // tile finished: Cr' = N1 + P2, Ci' = N3 - N1 + P2; plain stores stay in flight while the next tile starts
+    // tile finished: Cr' = N1 + P2, Ci' = N3 - N1 + P2; plain stores stay in flight while the next tile starts.
+    // Full tiles address their 16 stores as (scalar tile origin + scalar unit offset) + the constant per-lane 32-bit offset
+    // the C-slice DMA uses: no VALU address arithmetic (the generic form cost ~10 VALU instructions per store, three of them
+    // integer multiplies, in the phase where the SIMD partner streams MFMAs: 10 % of the kernel, tools/gemm_trace ablation)
     cplx* Cs = A + (size_t)cs * sys_stride;
     const int row0 = tg.row_begin + cty * BM3, col0 = tg.col_begin + ctx * BN3;
     const bool full = row0 + BM3 <= n_pad && col0 + BN3 <= n_cols;
+    if (full) {
+      char* tb = (char*)(Cs + (size_t)row0 * lda + col0);
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
+      for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const int col = col0 + wn * 32 + n * 16 + l15;
+        for (int n = 0; n < 2; ++n) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = row0 + wm * 32 + tm * 16 + 4 * g + l4;
-          const cplx v = make_double2(N1[tm][n][g] + P2[tm][n][g], N3[tm][n][g] - N1[tm][n][g] + P2[tm][n][g]);
-          if (full) Cs[(size_t)row * lda + col] = v;
-          else if (col < n_cols && row < n_pad) Cs[(size_t)row * lda + col] = v;
-          N1[tm][n][g] = 0.0; P2[tm][n][g] = 0.0; N3[tm][n][g] = 0.0;
+          for (int g = 0; g < 4; ++g) {
+            const long long du = ((long long)(tm * 16 + 4 * g) * lda + n * 16) * (long long)sizeof(cplx);
+#ifdef BIEM_ABL_NOEPI
+            asm volatile("" ::"v"(N1[tm][n][g]), "v"(P2[tm][n][g]), "v"(N3[tm][n][g]));   // keep the MFMAs alive
+#else
+            const cplx v = make_double2(N1[tm][n][g] + P2[tm][n][g], N3[tm][n][g] - N1[tm][n][g] + P2[tm][n][g]);
+            *(cplx*)(tb + du + offC) = v;
+#endif
+            N1[tm][n][g] = 0.0; P2[tm][n][g] = 0.0; N3[tm][n][g] = 0.0;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const int col = col0 + wn * 32 + n * 16 + l15;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = row0 + wm * 32 + tm * 16 + 4 * g + l4;
+            const cplx v = make_double2(N1[tm][n][g] + P2[tm][n][g], N3[tm][n][g] - N1[tm][n][g] + P2[tm][n][g]);
+            if (col < n_cols && row < n_pad) Cs[(size_t)row * lda + col] = v;
+            N1[tm][n][g] = 0.0; P2[tm][n][g] = 0.0; N3[tm][n][g] = 0.0;
+          }
         }
       }
     }
@@ -763,7 +731,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
     stores_pending = full ? 1 : 2;
     cs = p_s; cty = p_ty; ctx = p_tx;
   }
-#ifdef BIEM_GEMM_TRACE
+#ifdef BIEM_TR_STAMPS
   __syncthreads();
   if (blockIdx.x < 4) {     // 4 workgroups x 4 waves
     if (lane == 0) s_tr[wave * 512 + 7] = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4);     // HW_ID[15:0]
@@ -783,11 +751,7 @@ static void launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, l
   tg.ty_n = (rrows + BM3 - 1) / BM3; tg.tx_n = (rcols + BN3 - 1) / BN3;
   tg.per_sys = tg.ty_n * tg.tx_n; tg.full_bands = tg.ty_n / 8; tg.ntiles = tg.per_sys * nb;
   tg.row_begin = row_begin; tg.row_end = row_end; tg.col_begin = col_begin; tg.col_end = col_end; tg.brow = brow;
-#ifdef BIEM_GRID_CAP
-  const int cap = BIEM_GRID_CAP;               // experiment
-#else
   const int cap = 512;                         // persistent grid: 2 workgroups per CU
-#endif
   int want = (tg.ntiles + 7) / 8 * 8;          // one workgroup per tile up to the cap, multiple of 8
   int grid = want < cap ? want : cap;
   ProfScope ps(prof_class, st, prof_work >= 0.0 ? prof_work : 8.0 * (double)nb * rrows * (double)rcols * kd);
