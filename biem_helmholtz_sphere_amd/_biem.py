@@ -285,7 +285,7 @@ def plane_wave(*, k: Array, direction: Array) -> Tuple[Callable[[Array], Array],
 def point_source(*, k: Array, source: Array, n: int) -> Tuple[Callable[[Array], Array], Callable[[Array], Array]]:
     r"""Point source :math:`u(x) = h^{(1)}_n(k\|x - source\|)` with the d-dimensional h_n (reference :391-450).
 
-    The radial functions are evaluated by the HIP kernel behind ``biem_radial`` (real k).
+    The radial functions are evaluated by the HIP kernel behind ``biem_radial_complex`` (real or complex k).
     """
     k_ = k if isinstance(k, torch.Tensor) else np.asarray(k)
     s_ = source if isinstance(source, torch.Tensor) else np.asarray(source, dtype=np.float64)
@@ -296,15 +296,13 @@ def point_source(*, k: Array, source: Array, n: int) -> Tuple[Callable[[Array], 
     n = int(n)
 
     def _radial(d: int, z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """h_n(z), h_n'(z) for a real tensor z on a cuda device."""
+        """h_n(z), h_n'(z) for a (real or complex) tensor z on a cuda device."""
         lib = L.load()
-        zz = z.to(torch.float64).contiguous().reshape(-1)
-        out = torch.empty((zz.numel(), 2, n + 2), dtype=torch.float64, device=zz.device)
+        zz = z.to(torch.complex128).contiguous().reshape(-1)
+        out = torch.empty((zz.numel(), 2, n + 2), dtype=torch.complex128, device=zz.device)
         with torch.cuda.device(zz.device):
-            L.check(lib.biem_radial(d, n + 1, zz.numel(), _ptr(zz), _ptr(out), _stream_ptr(zz.device)), "biem_radial")
-        j, y = out[:, 0, :], out[:, 1, :]
-        h = torch.complex(j[:, n], y[:, n])
-        h1 = torch.complex(j[:, n + 1], y[:, n + 1])
+            L.check(lib.biem_radial_complex(d, n + 1, zz.numel(), _ptr(zz), _ptr(out), _stream_ptr(zz.device)), "biem_radial_complex")
+        h, h1 = out[:, 1, n], out[:, 1, n + 1]
         hp = n / zz * h - h1
         return h.reshape(z.shape), hp.reshape(z.shape)
 
@@ -313,7 +311,7 @@ def point_source(*, k: Array, source: Array, n: int) -> Tuple[Callable[[Array], 
         dev = _compute_device(None if was_np else x.device)
         xt = _to_dev(x, dev, torch.float64)
         st = _to_dev(s_, dev, torch.float64)
-        kt = _to_dev(k_, dev, torch.float64)
+        kt = _to_dev(k_, dev, torch.complex128 if _is_complex(k_) else torch.float64)
         rel = xt - st[(slice(None),) + (None,) * (xt.ndim - st.ndim)]
         r = torch.linalg.vector_norm(rel, dim=0)
         return was_np, (None if was_np else x.device), rel, r, kt
@@ -391,8 +389,6 @@ def _validate_biem_inputs(c, centers, radii, k, eta, alpha, beta) -> Tuple[int, 
             raise TypeError(f"{nm} must be an array (torch.Tensor or numpy.ndarray), got {type(a).__name__}")
     if eta is not None and _is_complex(eta):
         raise ValueError("The decoupling parameter must be real.")
-    if _is_complex(k):
-        raise NotImplementedError("complex wavenumbers are not built yet in the MI355X kernels (SURVEY 8(f) item 3)")
     ks, cs, rs = _shape(k), _shape(centers), _shape(radii)
     es = (1,) * len(ks) if eta is None else _shape(eta)
     als = _shape(alpha) or (1,) * (len(ks) + 1)
@@ -432,7 +428,7 @@ def _check_biem_inputs(c, centers, radii, k, eta, alpha, beta):
     f64 = torch.float64
     centers_t = _to_dev(centers, dev, f64)
     radii_t = _to_dev(radii, dev, f64)
-    k_t = _to_dev(k, dev, f64)
+    k_t = _to_dev(k, dev, torch.complex128)     # the kernels take complex wavenumbers (Im k = 0: real special functions)
     if eta is None:
         eta_t = torch.ones((1,) * k_t.ndim, dtype=f64, device=dev)
     else:
@@ -452,7 +448,7 @@ def _check_biem_inputs(c, centers, radii, k, eta, alpha, beta):
             UserWarning,
             stacklevel=3,
         )
-    if bool(torch.any(eta_t * k_t < 0)):
+    if bool(torch.any(k_t.imag < 0)) or bool(torch.any(eta_t * k_t.real < 0)):
         warnings.warn("The solution may be incorrectif not (Im k >= 0 and eta Re k >= 0).", UserWarning, stacklevel=3)
     return origin, dev, batch, centers_t, radii_t, k_t, eta_t, alpha_t, beta_t
 
@@ -668,7 +664,7 @@ def biem(
         c=c,
         centers=real_out(torch.movedim(centers_t, -1, 0)),       # [..., B, v] -> [v, ..., B]  (reference :588)
         radii=real_out(radii_t),
-        k=real_out(k_t),
+        k=(origin.give(k_t) if _is_complex(k) else real_out(k_t.real)),
         n_end=n_end,
         eta=real_out(eta_t),
         kind=kind,
@@ -696,7 +692,7 @@ def biem_u(res: Any, x: Array, /, far_field: bool = False, per_ball: bool = Fals
         origin.real_dtype = torch.float32
     lib = L.load()
     f64 = torch.float64
-    k_t = _to_dev(res.k, dev, f64)
+    k_t = _to_dev(res.k, dev, torch.complex128)
     eta_t = _to_dev(res.eta, dev, f64)
     cen_t = _to_dev(res.centers, dev, f64)[list(perm)]   # [d, ...(first), B], canonical axes
     rad_t = _to_dev(res.radii, dev, f64)            # [...(first), B]

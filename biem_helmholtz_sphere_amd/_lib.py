@@ -33,6 +33,7 @@ SIGNATURES = {
     "biem_plan_projection": (_i, [_vp, _vp]),
     "biem_plan_terms": (_i, [_vp, _vp, _vp, _vp]),
     "biem_radial": (_i, [_i, _i, _i, _dp, _dp, _vp]),
+    "biem_radial_complex": (_i, [_i, _i, _i, _dp, _dp, _vp]),
     "biem_harmonics": (_i, [_vp, _i, _dp, _dp, _vp]),
     "biem_ball_tables": (_i, [_vp, _i, _i, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _vp]),
     "biem_rhs_project": (_i, [_vp, _i, _i, _i, _dp, _dp, _ll, _ll, _ll, _vp]),

@@ -107,6 +107,11 @@ int biem_radial(int d, int nmax, int count, const double* d_x, double* d_out, vo
   return launch_radial(d, nmax, count, d_x, d_out, (hipStream_t)stream);
 }
 
+int biem_radial_complex(int d, int nmax, int count, const double* d_z, double* d_out, void* stream) {
+  NEED(d_z, "d_z"); NEED(d_out, "d_out");
+  return launch_radial_c(d, nmax, count, d_z, d_out, (hipStream_t)stream);
+}
+
 int biem_harmonics(const biem_plan* plan, int count, const double* d_u, double* d_Y, void* stream) {
   NEED_DEV(plan); NEED(d_u, "d_u"); NEED(d_Y, "d_Y");
   return launch_harmonics(plan, count, d_u, d_Y, (hipStream_t)stream);
@@ -222,7 +227,7 @@ int biem_solve(const biem_plan* plan, int nb, int B, int nrhs, const double* d_k
   if (rc) return rc;
   for (int s0 = 0; s0 < nb; s0 += L.chunk) {
     const int c = (nb - s0 < L.chunk) ? nb - s0 : L.chunk;
-    const double* ks = d_k + s0;
+    const double* ks = d_k + 2 * (size_t)s0;   // complex128 per system
     const double* cen = d_centers + (geom_batched ? (size_t)s0 * B * d : 0);
     const double* tb = tab + (size_t)s0 * B * 3 * plan->n_end * 2;
     // right-hand side into column n_pad of the augmented matrix (padded rows: zero via fill_pad? -> set explicitly below)

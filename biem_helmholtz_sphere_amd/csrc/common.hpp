@@ -68,6 +68,7 @@ struct ProfScope {
 
 // launch wrappers implemented in the .hip files (all stream-ordered, no syncs)
 int launch_radial(int d, int nmax, int count, const double* d_x, double* d_out, hipStream_t st);
+int launch_radial_c(int d, int nmax, int count, const double* d_z, double* d_out, hipStream_t st);
 int launch_harmonics(const biem_plan* p, int count, const double* d_u, double* d_Y, hipStream_t st);
 int launch_ball_tables(const biem_plan* p, int nb, int B, const double* d_k, const double* d_eta, const double* d_radii,
                        int geom_batched, const double* d_alpha, const double* d_beta, int ab_batched, double* d_tab, hipStream_t st);

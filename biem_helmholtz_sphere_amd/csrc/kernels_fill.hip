@@ -30,6 +30,25 @@ __global__ void k_radial(int d, int nmax, int count, const double* __restrict__ 
   }
 }
 
+// complex arguments: out[i][0][n] = z_n (regular), out[i][1][n] = h_n (outgoing), complex128
+__global__ void k_radial_c(int d, int nmax, int count, const cplx* __restrict__ z, cplx* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  cplx lj[kMaxRad + 3], lh[kMaxRad + 3];
+  radial_jh(d, nmax, z[i], lj, lh);
+  cplx* J = out + (size_t)i * 2 * (nmax + 1);
+  cplx* Hh = J + (nmax + 1);
+  for (int n = 0; n <= nmax; ++n) { J[n] = lj[n]; Hh[n] = lh[n]; }
+}
+
+int launch_radial_c(int d, int nmax, int count, const double* d_z, double* d_out, hipStream_t st) {
+  if (nmax < 0 || nmax > kMaxRad || (d != 2 && d != 3 && d != 4)) { set_error("biem_radial_complex: bad d/nmax"); return BIEM_ERR_ARG; }
+  if (count <= 0) return BIEM_OK;
+  hipLaunchKernelGGL(k_radial_c, dim3((count + 63) / 64), dim3(64), 0, st, d, nmax, count, (const cplx*)d_z, (cplx*)d_out);
+  BIEM_LAUNCHCHK();
+  return BIEM_OK;
+}
+
 int launch_radial(int d, int nmax, int count, const double* d_x, double* d_out, hipStream_t st) {
   if (nmax < 0 || nmax > kMaxRad || (d != 2 && d != 3 && d != 4)) { set_error("biem_radial: bad d/nmax"); return BIEM_ERR_ARG; }
   if (count <= 0) return BIEM_OK;
@@ -67,35 +86,36 @@ int launch_harmonics(const biem_plan* p, int count, const double* d_u, double* d
 //   (ush.harmonics_regular_singular_component x4 + potential_coef S/D, _biem.py:723-789)
 // one thread per (system, ball); outputs tab[s][b][3][n_end] complex.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_ball_tables(int d, int n_end, int nb, int B, const double* __restrict__ k, const double* __restrict__ eta,
+__global__ void k_ball_tables(int d, int n_end, int nb, int B, const cplx* __restrict__ k, const double* __restrict__ eta,
                               const double* __restrict__ radii, int geom_batched, const cplx* __restrict__ alpha,
                               const cplx* __restrict__ beta, int ab_batched, cplx* __restrict__ tab) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nb * B) return;
   int s = i / B, b = i % B;
-  double kk = k[s], et = eta[s];
+  const cplx kk = k[s];
+  const double et = eta[s];
   double rho = radii[(geom_batched ? (size_t)s * B : 0) + b];
   cplx al = alpha[(ab_batched ? (size_t)s * B : 0) + b];
   cplx be = beta[(ab_batched ? (size_t)s * B : 0) + b];
-  double J[kMaxRad + 3], Y[kMaxRad + 3];
-  double x = kk * rho;
-  radial_d(d, n_end, x, J, Y);   // orders 0..n_end (one extra for the derivative)
+  cplx J[kMaxRad + 3], Hh[kMaxRad + 3];
+  const cplx x = cscale(kk, rho);
+  radial_jh(d, n_end, x, J, Hh);   // orders 0..n_end (one extra for the derivative); Im k = 0 takes the real routines
+  const cplx ix = crecip(x);
   cplx* out = tab + (size_t)i * 3 * n_end;
   double rp = 1.0;               // rho^{d-1}
   for (int q = 0; q < d - 1; ++q) rp *= rho;
-  double kd2 = 1.0;              // k^{d-2}
-  for (int q = 0; q < d - 2; ++q) kd2 *= kk;
+  cplx kd2 = make_double2(1.0, 0.0);   // k^{d-2}
+  for (int q = 0; q < d - 2; ++q) kd2 = cmul(kd2, kk);
   for (int n = 0; n < n_end; ++n) {
-    double j = J[n], y = Y[n];
-    double jp = (double)n / x * j - J[n + 1];
-    double yp = (double)n / x * y - Y[n + 1];
-    // gj = alpha j + beta k j'
-    cplx gj = make_double2(al.x * j + be.x * kk * jp, al.y * j + be.y * kk * jp);
-    // gh = alpha (j + i y) + beta k (j' + i y')
-    cplx h = make_double2(j, y), hp = make_double2(kk * jp, kk * yp);
-    cplx gh = cadd(cmul(al, h), cmul(be, hp));
+    const cplx j = J[n], h = Hh[n];
+    const cplx jp = csub(cscale(cmul(ix, j), (double)n), J[n + 1]);
+    const cplx hp = csub(cscale(cmul(ix, h), (double)n), Hh[n + 1]);
+    const cplx kjp = cmul(kk, jp), khp = cmul(kk, hp);
+    // gj = alpha j + beta k j',  gh = alpha h + beta k h'
+    cplx gj = cadd(cmul(al, j), cmul(be, kjp));
+    cplx gh = cadd(cmul(al, h), cmul(be, khp));
     // blc = i k^{d-1} rho^{d-1} j' - i eta * i k^{d-2} rho^{d-1} j = k^{d-2} rho^{d-1} (eta j + i k j')
-    cplx blc = make_double2(kd2 * rp * et * j, kd2 * rp * kk * jp);
+    cplx blc = cscale(cmul(kd2, make_double2(et * j.x - kjp.y, et * j.y + kjp.x)), rp);
     out[n] = gj;
     out[n_end + n] = gh;
     out[2 * n_end + n] = blc;
@@ -108,7 +128,7 @@ int launch_ball_tables(const biem_plan* p, int nb, int B, const double* d_k, con
   int total = nb * B;
   if (total <= 0) return BIEM_OK;
   ProfScope ps(PK_TABLES, st);
-  hipLaunchKernelGGL(k_ball_tables, dim3((total + 63) / 64), dim3(64), 0, st, p->d, p->n_end, nb, B, d_k, d_eta, d_radii,
+  hipLaunchKernelGGL(k_ball_tables, dim3((total + 63) / 64), dim3(64), 0, st, p->d, p->n_end, nb, B, (const cplx*)d_k, d_eta, d_radii,
                      geom_batched, (const cplx*)d_alpha, (const cplx*)d_beta, ab_batched, (cplx*)d_tab);
   BIEM_LAUNCHCHK();
   return BIEM_OK;
@@ -122,10 +142,10 @@ int launch_ball_tables(const biem_plan* p, int nb, int B, const double* d_k, con
 // the inf/nan afterwards, _biem.py:745-746).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int H2, double Cd, const int* __restrict__ labels2,
-                                                     const int* __restrict__ deg2, int B, const double* __restrict__ k,
+                                                     const int* __restrict__ deg2, int B, const cplx* __restrict__ k,
                                                      const double* __restrict__ centers, int geom_batched, cplx* __restrict__ T) {
-  __shared__ double sJ[kMaxRad * 2 + 6];
-  __shared__ double sY[kMaxRad * 2 + 6];
+  __shared__ cplx sJ[kMaxRad * 2 + 6];
+  __shared__ cplx sH[kMaxRad * 2 + 6];
   int pair = blockIdx.x, s = blockIdx.y;
   int b = pair / B, bp = pair % B;
   if (b == bp) return;
@@ -135,7 +155,7 @@ __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int
   double r2 = 0.0;
   for (int i = 0; i < d; ++i) { t[i] = cb[i] - cp[i]; r2 += t[i] * t[i]; }
   double r = sqrt(r2);
-  if (threadIdx.x == 0) radial_d(d, n2 - 1, k[s] * r, sJ, sY);
+  if (threadIdx.x == 0) radial_jh(d, n2 - 1, cscale(k[s], r), sJ, sH);
   __syncthreads();
   Dir dir = make_dir(tree, t);
   cplx* out = T + ((size_t)s * B * B + pair) * H2;
@@ -143,8 +163,7 @@ __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int
     double re, im;
     harmonic_single(tree, labels2[3 * l], labels2[3 * l + 1], labels2[3 * l + 2], dir, &re, &im);
     int n = deg2[l];
-    cplx h = make_double2(Cd * sJ[n], Cd * sY[n]);
-    out[l] = cmul(h, make_double2(re, im));
+    out[l] = cmul(cscale(sH[n], Cd), make_double2(re, im));
   }
 }
 
@@ -262,7 +281,7 @@ int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const doub
   ProfScope ps(PK_FILL, st, 16.0 * (double)nb * N * (double)N);
   if (B > 1) {
     hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2,
-                       p->d_deg2, B, d_k, d_centers, geom_batched, T);
+                       p->d_deg2, B, (const cplx*)d_k, d_centers, geom_batched, T);
     BIEM_LAUNCHCHK();
   }
   size_t shm = (size_t)(p->H2 + H) * sizeof(cplx) + (size_t)p->chunk_terms_max * 10 + (size_t)(p->chunk_ents_max + 1) * 4 + 16;

@@ -11,22 +11,24 @@ constexpr int kMaxRadU = 320;
 
 // c[s][b][h] = density * blc_{n(h)}(rho_b): one wave per (system, ball)
 __global__ void __launch_bounds__(64) k_uscat_coef(int d, int H, int n_end, const int* __restrict__ deg, int B,
-                                                    const double* __restrict__ k, const double* __restrict__ eta,
+                                                    const cplx* __restrict__ k, const double* __restrict__ eta,
                                                     const double* __restrict__ radii, int geom_batched,
                                                     const cplx* __restrict__ dens, cplx* __restrict__ c) {
-  __shared__ double sJ[kMaxRadU + 3], sY[kMaxRadU + 3];
+  __shared__ cplx sJ[kMaxRadU + 3], sH[kMaxRadU + 3];
   __shared__ cplx sB[kMaxRadU];
   int b = blockIdx.x, s = blockIdx.y;
-  double kk = k[s], et = eta[s];
+  const cplx kk = k[s];
+  const double et = eta[s];
   double rho = radii[(geom_batched ? (size_t)s * B : 0) + b];
   if (threadIdx.x == 0) {
-    double x = kk * rho;
-    radial_d(d, n_end, x, sJ, sY);
+    const cplx x = cscale(kk, rho), ix = crecip(x);
+    radial_jh(d, n_end, x, sJ, sH);
     double rp = 1.0; for (int q = 0; q < d - 1; ++q) rp *= rho;
-    double kd2 = 1.0; for (int q = 0; q < d - 2; ++q) kd2 *= kk;
+    cplx kd2 = make_double2(1.0, 0.0); for (int q = 0; q < d - 2; ++q) kd2 = cmul(kd2, kk);
     for (int n = 0; n < n_end; ++n) {
-      double j = sJ[n], jp = (double)n / x * j - sJ[n + 1];
-      sB[n] = make_double2(kd2 * rp * et * j, kd2 * rp * kk * jp);   // blc = k^{d-2} rho^{d-1} (eta j + i k j')
+      const cplx j = sJ[n];
+      const cplx kjp = cmul(kk, csub(cscale(cmul(ix, j), (double)n), sJ[n + 1]));
+      sB[n] = cscale(cmul(kd2, make_double2(et * j.x - kjp.y, et * j.y + kjp.x)), rp);   // blc = k^{d-2} rho^{d-1} (eta j + i k j')
     }
   }
   __syncthreads();
@@ -40,11 +42,11 @@ __device__ inline double wave_sum(double v) {
 }
 
 __global__ void __launch_bounds__(256) k_uscat(int tree, int d, int H, int n_end, const int* __restrict__ labels,
-                                                const int* __restrict__ deg, int nb, int B, int P, const double* __restrict__ k,
+                                                const int* __restrict__ deg, int nb, int B, int P, const cplx* __restrict__ k,
                                                 const double* __restrict__ centers, const double* __restrict__ radii,
                                                 int geom_batched, const cplx* __restrict__ c, const double* __restrict__ pts,
                                                 int flags, cplx* __restrict__ out) {
-  __shared__ double sJ[4][kMaxRadU + 3], sY[4][kMaxRadU + 3];
+  __shared__ cplx sJ[4][kMaxRadU + 3], sH[4][kMaxRadU + 3];
   __shared__ int sBad;
   extern __shared__ cplx sBall[];   // [B]
   const int p = blockIdx.x, s = blockIdx.y;
@@ -54,7 +56,7 @@ __global__ void __launch_bounds__(256) k_uscat(int tree, int d, int H, int n_end
   if (threadIdx.x == 0) sBad = 0;
   double x[4];
   for (int i = 0; i < d; ++i) x[i] = pb ? pts[((size_t)i * P + p) * nb + s] : pts[(size_t)i * P + p];
-  const double kk = k[s];
+  const cplx kk = k[s];
   __syncthreads();
   for (int bb = 0; bb < B; bb += 4) {
     const int b = bb + wave;
@@ -68,7 +70,7 @@ __global__ void __launch_bounds__(256) k_uscat(int tree, int d, int H, int n_end
       r = sqrt(r2);
       if (lane == 0 && !far) {
         if ((!inner && r < rho) || (inner && r > rho)) atomicOr(&sBad, 1);
-        if (r > 0.0) radial_d(d, n_end - 1, kk * r, sJ[wave], sY[wave]);
+        if (r > 0.0) radial_jh(d, n_end - 1, cscale(kk, r), sJ[wave], sH[wave]);
       }
     }
     __syncthreads();
@@ -86,7 +88,7 @@ __global__ void __launch_bounds__(256) k_uscat(int tree, int d, int H, int n_end
           int q = n & 3;
           rad = q == 0 ? make_double2(1, 0) : q == 1 ? make_double2(0, -1) : q == 2 ? make_double2(-1, 0) : make_double2(0, 1);
         } else {
-          rad = make_double2(sJ[wave][n], sY[wave][n]);
+          rad = sH[wave][n];
         }
         cplx v = cmul(cmul(cs[h], rad), make_double2(yr, yi));
         ar += v.x; ai += v.y;
@@ -95,11 +97,11 @@ __global__ void __launch_bounds__(256) k_uscat(int tree, int d, int H, int n_end
       if (lane == 0) {
         cplx v = make_double2(ar, ai);
         if (far) {
-          // e^{-i k x.c_b} / (i k)^{(d-1)/2},   (i k)^p = k^p e^{i pi p / 2}  (k > 0)
-          double pw = 0.5 * (d - 1);
-          double mag = pow(kk, -pw);
-          double ang = -kk * xc - 0.5 * kPi * pw;
-          v = cmul(v, make_double2(mag * cos(ang), mag * sin(ang)));
+          // e^{-i k x.c_b} / (i k)^{(d-1)/2} = exp(-i k x.c_b - p log(i k)),  p = (d-1)/2, principal branch (k > 0 real:
+          // |k|^{-p} e^{-i (k x.c_b + pi p / 2)})
+          const double pw = 0.5 * (d - 1);
+          const cplx lik = zlog(make_double2(-kk.y, kk.x));                    // log(i k)
+          v = cmul(v, zexp(make_double2(kk.y * xc - pw * lik.x, -kk.x * xc - pw * lik.y)));
         }
         sBall[b] = v;
       }
@@ -126,11 +128,11 @@ int launch_uscat(const biem_plan* p, int nb, int B, int P, const double* d_k, co
   size_t need = (size_t)nb * B * p->H * sizeof(cplx);
   if (work_bytes < need) { set_error("biem_uscat: workspace too small"); return BIEM_ERR_ARG; }
   cplx* c = (cplx*)d_work;
-  hipLaunchKernelGGL(k_uscat_coef, dim3(B, nb), dim3(64), 0, st, p->d, p->H, p->n_end, p->d_deg, B, d_k, d_eta, d_radii,
+  hipLaunchKernelGGL(k_uscat_coef, dim3(B, nb), dim3(64), 0, st, p->d, p->H, p->n_end, p->d_deg, B, (const cplx*)d_k, d_eta, d_radii,
                      geom_batched, (const cplx*)d_density, c);
   BIEM_LAUNCHCHK();
   hipLaunchKernelGGL(k_uscat, dim3(P, nb), dim3(256), (size_t)B * sizeof(cplx), st, p->tree, p->d, p->H, p->n_end, p->d_labels,
-                     p->d_deg, nb, B, P, d_k, d_centers, d_radii, geom_batched, (const cplx*)c, d_points, flags, (cplx*)d_out);
+                     p->d_deg, nb, B, P, (const cplx*)d_k, d_centers, d_radii, geom_batched, (const cplx*)c, d_points, flags, (cplx*)d_out);
   BIEM_LAUNCHCHK();
   return BIEM_OK;
 }

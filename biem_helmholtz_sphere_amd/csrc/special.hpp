@@ -130,6 +130,210 @@ BIEM_HD void radial_d(int d, int nmax, double x, double* J, double* Y) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Complex argument (complex wavenumber, reference gui.py:296-301).  Outputs are the regular functions z_n = J and the
+// OUTGOING ones h_n = j_n + i y_n directly: for Im z > 0 both j and y grow like e^{Im z} while h decays, so h is never
+// formed as a sum.  (zc = double2: .x real, .y imaginary.)
+//   d = 3 : j_n by Miller's backward recurrence normalised with the larger of j_0 = sin z / z, j_1;  h_0 = -i e^{iz}/z,
+//           h_1 = -(z + i) e^{iz}/z^2, h_n by forward recurrence (h is the dominant solution in n).
+//   d = 2,4: J_n by Miller's recurrence normalised with e^{-+iz} = J_0 + 2 sum_k (-+i)^k J_k (the sign that makes the
+//           right-hand side the large exponential); H_0, H_1 from the modified functions K_0, K_1 at w = -iz:
+//           H_0 = (2/(pi i)) K_0(w), H_1 = -(2/pi) K_1(w), with K by power series for |w| <= 2 and Steed's continued
+//           fraction (CF2) otherwise; Im z < 0 through H1(z) = 2 J(z) - conj(H1(conj z)).  H_n by forward recurrence.
+// ---------------------------------------------------------------------------------------------
+typedef double2 zc;
+BIEM_HD zc zmk(double a, double b) { zc r; r.x = a; r.y = b; return r; }
+BIEM_HD zc zadd(zc a, zc b) { return zmk(a.x + b.x, a.y + b.y); }
+BIEM_HD zc zsub(zc a, zc b) { return zmk(a.x - b.x, a.y - b.y); }
+BIEM_HD zc zmul(zc a, zc b) { return zmk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+BIEM_HD zc zscl(zc a, double s) { return zmk(a.x * s, a.y * s); }
+BIEM_HD zc zinv(zc a) {
+  if (fabs(a.x) >= fabs(a.y)) { double r = a.y / a.x, den = a.x + a.y * r; return zmk(1.0 / den, -r / den); }
+  double r = a.x / a.y, den = a.x * r + a.y;
+  return zmk(r / den, -1.0 / den);
+}
+BIEM_HD zc zdiv(zc a, zc b) { return zmul(a, zinv(b)); }
+BIEM_HD double zabs1(zc a) { return fabs(a.x) + fabs(a.y); }
+BIEM_HD zc zexp(zc a) { double e = exp(a.x); return zmk(e * cos(a.y), e * sin(a.y)); }
+BIEM_HD zc zlog(zc a) { return zmk(log(hypot(a.x, a.y)), atan2(a.y, a.x)); }
+BIEM_HD zc zsqrt(zc a) {
+  double m = hypot(a.x, a.y);
+  if (m == 0.0) return zmk(0.0, 0.0);
+  double re = sqrt(0.5 * (m + fabs(a.x)));
+  double im = 0.5 * a.y / re;
+  return a.x >= 0.0 ? zmk(re, im) : zmk(fabs(im), a.y >= 0.0 ? re : -re);
+}
+// sin z, cos z without overflow for the sizes met here (|Im z| < 700)
+BIEM_HD void zsincos(zc z, zc* s, zc* c) {
+  double sh = sinh(z.y), ch = cosh(z.y), sn = sin(z.x), cs = cos(z.x);
+  *s = zmk(sn * ch, cs * sh);
+  *c = zmk(cs * ch, -sn * sh);
+}
+
+BIEM_HD int miller_start(int nmax, double az) {
+  int M = (int)az;
+  if (M < nmax + 1) M = nmax + 1;
+  return M + 32 + (int)sqrt(48.0 * (double)M);
+}
+
+// spherical j_0..j_nmax, h_0..h_nmax at complex z != 0
+BIEM_HD void bessel_jh_sph_c(int nmax, zc z, zc* J, zc* H) {
+  const int M = miller_start(nmax, hypot(z.x, z.y));
+  const double big = 1e200, small = 1e-200;
+  zc jp1 = zmk(0.0, 0.0), jc = zmk(1e-250, 0.0);
+  const zc iz = zinv(z);
+  for (int k = M; k >= 1; --k) {
+    zc jm1 = zsub(zscl(zmul(iz, jc), (double)(2 * k + 1)), jp1);
+    if (k <= nmax) J[k] = jc;
+    jp1 = jc;
+    jc = jm1;
+    if (zabs1(jc) > big) {
+      jc = zscl(jc, small); jp1 = zscl(jp1, small);
+      for (int q = (k <= nmax ? k : nmax + 1); q <= nmax; ++q) J[q] = zscl(J[q], small);
+    }
+  }
+  J[0] = jc;
+  zc sn, cs;
+  zsincos(z, &sn, &cs);
+  zc j0 = zmul(sn, iz), j1 = zmul(zsub(zmul(sn, iz), cs), iz);
+  zc scale = (zabs1(j0) >= zabs1(j1)) ? zdiv(j0, jc) : zdiv(j1, jp1);
+  for (int q = 0; q <= nmax; ++q) J[q] = zmul(J[q], scale);
+  // h_0 = -i e^{iz} / z,  h_1 = -(z + i) e^{iz} / z^2
+  zc e = zexp(zmk(-z.y, z.x));
+  zc h0 = zmul(zmk(e.y, -e.x), iz);                         // -i e
+  zc h1 = zmul(zmul(zmk(-(z.x), -(z.y + 1.0)), e), zmul(iz, iz));
+  H[0] = h0;
+  if (nmax >= 1) H[1] = h1;
+  for (int n = 1; n < nmax; ++n) {
+    zc h2 = zsub(zscl(zmul(iz, h1), (double)(2 * n + 1)), h0);
+    H[n + 1] = h2;
+    h0 = h1; h1 = h2;
+  }
+}
+
+// K_0(w), K_1(w) for complex w, Re w >= 0, w != 0
+BIEM_HD void bessel_k01_c(zc w, zc* k0, zc* k1) {
+  if (hypot(w.x, w.y) <= 2.0) {
+    const zc t = zscl(zmul(w, w), 0.25);                    // w^2 / 4
+    const zc lg = zadd(zlog(zscl(w, 0.5)), zmk(kEulerGamma, 0.0));
+    zc term0 = zmk(1.0, 0.0), term1 = zmk(1.0, 0.0);       // t^k/(k!)^2, t^k/(k!(k+1)!)
+    zc i0 = term0, s0 = zmk(0.0, 0.0);                      // I_0, sum t^k/(k!)^2 H_k
+    zc i1 = term1, s1 = zscl(term1, 1.0);                   // sum t^k/(k!(k+1)!), sum ... (H_k + H_{k+1}),  k = 0: H_0 + H_1 = 1
+    double hk = 0.0;
+    for (int k = 1; k < 60; ++k) {
+      term0 = zscl(zmul(term0, t), 1.0 / ((double)k * (double)k));
+      term1 = zscl(zmul(term1, t), 1.0 / ((double)k * (double)(k + 1)));
+      hk += 1.0 / (double)k;
+      i0 = zadd(i0, term0);
+      s0 = zadd(s0, zscl(term0, hk));
+      i1 = zadd(i1, term1);
+      s1 = zadd(s1, zscl(term1, 2.0 * hk + 1.0 / (double)(k + 1)));
+      if (zabs1(term0) < 1e-18 * zabs1(i0)) break;
+    }
+    *k0 = zsub(s0, zmul(lg, i0));
+    zc halfw = zscl(w, 0.5);
+    // K_1 = 1/w + (ln(w/2) + gamma) I_1 - (w/4) s1,  I_1 = (w/2) i1
+    *k1 = zsub(zadd(zinv(w), zmul(lg, zmul(halfw, i1))), zmul(zscl(w, 0.25), s1));
+    return;
+  }
+  // Steed's algorithm for the second continued fraction (order 0), complex arithmetic
+  zc b = zscl(zadd(w, zmk(1.0, 0.0)), 2.0);
+  zc d = zinv(b), h = d, delh = d;
+  zc q1 = zmk(0.0, 0.0), q2 = zmk(1.0, 0.0);
+  const double a1 = 0.25;
+  zc q = zmk(a1, 0.0), c = zmk(a1, 0.0);
+  double a = -a1;
+  zc s = zadd(zmk(1.0, 0.0), zmul(q, delh));
+  for (int i = 2; i < 20000; ++i) {
+    a -= 2.0 * (double)(i - 1);
+    c = zscl(c, -a / (double)i);
+    zc qnew = zscl(zsub(q1, zmul(b, q2)), 1.0 / a);
+    q1 = q2; q2 = qnew;
+    q = zadd(q, zmul(c, qnew));
+    b = zadd(b, zmk(2.0, 0.0));
+    d = zinv(zadd(b, zscl(d, a)));
+    delh = zmul(zsub(zmul(b, d), zmk(1.0, 0.0)), delh);
+    h = zadd(h, delh);
+    zc dels = zmul(q, delh);
+    s = zadd(s, dels);
+    if (zabs1(dels) < 1e-17 * zabs1(s)) break;
+  }
+  h = zscl(h, a1);
+  zc pre = zmul(zsqrt(zscl(zinv(w), 0.5 * kPi)), zexp(zmk(-w.x, -w.y)));
+  *k0 = zdiv(pre, s);
+  *k1 = zmul(zmul(*k0, zsub(zadd(w, zmk(0.5, 0.0)), h)), zinv(w));
+}
+
+// integer order J_0..J_nmax, H^(1)_0..H^(1)_nmax at complex z != 0
+BIEM_HD void bessel_jh_int_c(int nmax, zc z, zc* J, zc* H) {
+  const int M = miller_start(nmax, hypot(z.x, z.y)) | 1;
+  const double big = 1e200, small = 1e-200;
+  zc jp1 = zmk(0.0, 0.0), jc = zmk(1e-250, 0.0);
+  const zc tz = zscl(zinv(z), 2.0);
+  const bool up = z.y >= 0.0;                              // normalise with e^{-iz} (Im z >= 0) or e^{+iz}
+  zc sum = zmk(0.0, 0.0);                                  // sum_{k>=1} (-+i)^k J_k
+  for (int k = M; k >= 1; --k) {
+    zc jm1 = zsub(zscl(zmul(tz, jc), (double)k), jp1);
+    // (-i)^k or (+i)^k times jc
+    int q4 = k & 3;
+    zc ph = q4 == 0 ? jc : q4 == 1 ? (up ? zmk(jc.y, -jc.x) : zmk(-jc.y, jc.x)) : q4 == 2 ? zmk(-jc.x, -jc.y)
+                                                                                          : (up ? zmk(-jc.y, jc.x) : zmk(jc.y, -jc.x));
+    sum = zadd(sum, ph);
+    if (k <= nmax) J[k] = jc;
+    jp1 = jc;
+    jc = jm1;
+    if (zabs1(jc) > big) {
+      jc = zscl(jc, small); jp1 = zscl(jp1, small); sum = zscl(sum, small);
+      for (int q = (k <= nmax ? k : nmax + 1); q <= nmax; ++q) J[q] = zscl(J[q], small);
+    }
+  }
+  J[0] = jc;
+  zc norm = zadd(jc, zscl(sum, 2.0));
+  zc target = up ? zexp(zmk(z.y, -z.x)) : zexp(zmk(-z.y, z.x));   // e^{-iz} or e^{+iz}
+  zc scale = zdiv(target, norm);
+  for (int q = 0; q <= nmax; ++q) J[q] = zmul(J[q], scale);
+  // H_0, H_1 at zz = z (Im z >= 0) or conj z
+  zc zz = up ? z : zmk(z.x, -z.y);
+  zc w = zmk(zz.y, -zz.x);                                 // -i zz
+  zc k0, k1;
+  bessel_k01_c(w, &k0, &k1);
+  zc h0 = zscl(zmk(k0.y, -k0.x), 2.0 / kPi);               // (2/(pi i)) K_0 = -(2 i/pi) K_0
+  zc h1 = zscl(k1, -2.0 / kPi);
+  const zc tzz = up ? tz : zmk(tz.x, -tz.y);
+  H[0] = h0;
+  if (nmax >= 1) H[1] = h1;
+  for (int n = 1; n < nmax; ++n) {
+    zc h2 = zsub(zscl(zmul(tzz, h1), (double)n), h0);
+    H[n + 1] = h2;
+    h0 = h1; h1 = h2;
+  }
+  if (!up) {                                               // H1(z) = 2 J(z) - conj(H1(conj z))
+    for (int n = 0; n <= nmax; ++n) H[n] = zsub(zscl(J[n], 2.0), zmk(H[n].x, -H[n].y));
+  }
+}
+
+// d-dimensional regular and outgoing radial functions at a complex argument; real arguments (Im z == 0) take the real
+// routines above (bit-identical to the real-k path).  J, H: nmax + 1 entries (d = 4: nmax + 2 slots each).
+BIEM_HD void radial_jh(int d, int nmax, zc z, zc* J, zc* H) {
+  if (z.y == 0.0) {
+    double* Jd = (double*)J;
+    double* Yd = (double*)H;
+    radial_d(d, nmax, z.x, Jd, Yd);        // reals in the first nmax + 1 (+1) doubles of each buffer
+    for (int n = nmax; n >= 0; --n) { double j = Jd[n], y = Yd[n]; J[n] = zmk(j, 0.0); H[n] = zmk(j, y); }
+    return;
+  }
+  if (d == 3) {
+    bessel_jh_sph_c(nmax, z, J, H);
+  } else if (d == 2) {
+    bessel_jh_int_c(nmax, z, J, H);
+    for (int n = 0; n <= nmax; ++n) { J[n] = zscl(J[n], kSqrtHalfPi); H[n] = zscl(H[n], kSqrtHalfPi); }
+  } else {
+    bessel_jh_int_c(nmax + 1, z, J, H);
+    zc f = zscl(zinv(z), kSqrtHalfPi);
+    for (int n = 0; n <= nmax; ++n) { J[n] = zmul(J[n + 1], f); H[n] = zmul(H[n + 1], f); }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Orthonormal building blocks (no Condon-Shortley phase; positive leading coefficients)
 // ---------------------------------------------------------------------------------------------
 // Pbar_n^m(x), int_{-1}^{1} Pbar^2 = 1; s = sqrt(1 - x^2) supplied by the caller.

@@ -84,13 +84,19 @@ int biem_plan_terms(const biem_plan* plan, long long* h_ptr /*[H*H+1]*/, double*
 /* ---- special functions on the device, exposed for parity tests (ultrasphere.shn1 / potential_coef) ---- */
 /* z[i][0..nmax] (j) and [nmax+1 .. 2nmax+1] (y): d-dimensional spherical Bessel functions at x[i] */
 int biem_radial(int d, int nmax, int count, const double* d_x, double* d_out /*[count][2][nmax+1]*/, void* stream);
+/* complex arguments z[i] (complex128): out[i][0][n] = z_n regular, out[i][1][n] = h_n = j_n + i y_n outgoing (complex128);
+ * h is computed directly (closed forms / modified Bessel functions), never as the cancelling sum j + i y */
+int biem_radial_complex(int d, int nmax, int count, const double* d_z /*[count] c128*/, double* d_out /*[count][2][nmax+1] c128*/,
+                        void* stream);
 /* Y[p][h] (complex128) at directions d_u[p][d] (need not be normalised) for all labels of degree < n_end */
 int biem_harmonics(const biem_plan* plan, int count, const double* d_u, double* d_Y /*[count][H] c128*/, void* stream);
 
+/* ---- wavenumbers: every d_k below is [nb] COMPLEX128 (re, im interleaved), the reference's k of dtype result_type(k, complex)
+ *      (gui.py:296-301 passes complex k); systems with Im k == 0 take the real-argument special functions. ---- */
 /* ---- per-ball tables (ush.harmonics_regular_singular_component + potential_coef, _biem.py:723-789) ----
  * d_tab[nb][B][3][n_end] complex128: [0] gj = alpha j_n + beta k j_n', [1] gh = alpha h_n + beta k h_n', [2] blc_n = dlc - i eta slc
  * geometry arrays are [nb][B]... when geom_batched != 0, else [B]... shared by all systems; alpha/beta likewise (ab_batched). */
-int biem_ball_tables(const biem_plan* plan, int nb, int B, const double* d_k, const double* d_eta,
+int biem_ball_tables(const biem_plan* plan, int nb, int B, const double* d_k /*c128*/, const double* d_eta,
                      const double* d_radii, int geom_batched, const double* d_alpha /*c128*/, const double* d_beta /*c128*/,
                      int ab_batched, double* d_tab, void* stream);
 
@@ -107,7 +113,7 @@ int biem_rhs_project(const biem_plan* plan, int nb, int B, int nrhs, const doubl
  * Npad x Npad block (columns >= Npad are left untouched: that is where the LU keeps right-hand sides).
  * d_tab from biem_ball_tables.  Workspace: biem_fill_workspace_bytes. */
 size_t biem_fill_workspace_bytes(const biem_plan* plan, int nb, int B);
-int biem_fill(const biem_plan* plan, int nb, int B, const double* d_k, const double* d_centers /*[nb or 1][B][d]*/,
+int biem_fill(const biem_plan* plan, int nb, int B, const double* d_k /*c128*/, const double* d_centers /*[nb or 1][B][d]*/,
               int geom_batched, const double* d_tab, int scaling, double* d_A, long long lda, long long sys_stride,
               int n_pad, void* d_work, size_t work_bytes, void* stream);
 
@@ -130,7 +136,7 @@ int biem_density(const biem_plan* plan, int nb, int B, int nrhs, const double* d
  * d_points[d][P] (or [d][P][nb] with BIEM_USCAT_POINTS_BATCHED); out[P][nb] or [P][nb][B] (per ball), complex128.
  * Workspace: biem_uscat_workspace_bytes (holds density * blc). */
 size_t biem_uscat_workspace_bytes(const biem_plan* plan, int nb, int B);
-int biem_uscat(const biem_plan* plan, int nb, int B, int P, const double* d_k, const double* d_eta,
+int biem_uscat(const biem_plan* plan, int nb, int B, int P, const double* d_k /*c128*/, const double* d_eta,
                const double* d_centers, const double* d_radii, int geom_batched, const double* d_density,
                const double* d_points, int flags, double* d_out, void* d_work, size_t work_bytes, void* stream);
 
@@ -138,7 +144,7 @@ int biem_uscat(const biem_plan* plan, int nb, int B, int P, const double* d_k, c
  *      chunks of `chunk` resident matrices (0 = choose); every system is factored once for its nrhs right-hand sides.
  *      d_g [nb][nrhs][B][Q] as in biem_rhs_project, d_density [nb][nrhs][B][H]. ---- */
 size_t biem_solve_workspace_bytes(const biem_plan* plan, int nb, int B, int nrhs, int chunk);
-int biem_solve(const biem_plan* plan, int nb, int B, int nrhs, const double* d_k, const double* d_eta, const double* d_centers,
+int biem_solve(const biem_plan* plan, int nb, int B, int nrhs, const double* d_k /*c128*/, const double* d_eta, const double* d_centers,
                const double* d_radii, int geom_batched, const double* d_alpha, const double* d_beta, int ab_batched,
                const double* d_g, double* d_density, int* d_info, int chunk, void* d_work, size_t work_bytes, void* stream);
 

@@ -82,6 +82,28 @@ def radial(nmax: int, d: int, x: float):
     return j[:-1], y[:-1], jp, yp
 
 
+def radial_h(nmax: int, d: int, x):
+    """Return (j, h, jp, hp), n = 0..nmax: regular z_n^{(d)}, outgoing h_n^{(d)} = j + i y, and derivatives.
+
+    Real x > 0 goes through :func:`radial`; complex x (complex wavenumber, reference gui.py:296-301) uses SciPy's
+    complex-argument Bessel / Hankel functions directly (h is NOT formed as j + i y there: for Im x > 0 both grow like
+    e^{Im x} while h decays, and the sum would cancel).
+    """
+    if not np.iscomplexobj(x) or complex(x).imag == 0.0:
+        j, y, jp, yp = radial(nmax, d, float(np.real(x)))
+        return j, j + 1j * y, jp, jp + 1j * yp
+    z = complex(x)
+    n = np.arange(nmax + 2)
+    nu = n + d / 2.0 - 1.0
+    pref = math.sqrt(math.pi / 2.0) / z ** (d / 2.0 - 1.0)
+    j = pref * sp.jv(nu, z)
+    h = pref * sp.hankel1(nu, z)
+    nn = n[:-1]
+    jp = nn / z * j[:-1] - j[1:]
+    hp = nn / z * h[:-1] - h[1:]
+    return j[:-1], h[:-1], jp, hp
+
+
 # --------------------------------------------------------------------------------------
 # Orthonormal building blocks
 # --------------------------------------------------------------------------------------
@@ -307,8 +329,7 @@ def translation_SR_quadrature(tr: Tree, n_end: int, k: float, t: np.ndarray) -> 
     d = tr.d
     Cd = (2 * math.pi) ** (d / 2.0) * math.sqrt(2.0 / math.pi)
     r = float(np.linalg.norm(t))
-    j, y, _, _ = radial(2 * n_end - 2, d, k * r)
-    hn = j + 1j * y
+    _, hn, _, _ = radial_h(2 * n_end - 2, d, k * r)
     Yt = tr.harmonics((np.asarray(t, dtype=np.float64) / r)[None, :], 2 * n_end - 1)[:, 0]  # [H2]
     F = ((1j ** deg2) * hn[deg2] * Yt) @ np.conj(Yq2)               # [Q]
     ph = 1j ** deg
@@ -382,8 +403,7 @@ def translation_SR_ba_dense(n_end: int, k: float, t: np.ndarray) -> np.ndarray:
     t = np.asarray(t, dtype=np.float64)
     r = float(np.linalg.norm(t))
     n2 = 2 * n_end - 1
-    j, y, _, _ = radial(n2 - 1, 3, k * r)
-    hn = j + 1j * y
+    _, hn, _, _ = radial_h(n2 - 1, 3, k * r)
     u = t / r
     G, nn, mm = _gaunt3(n_end)
     Pb = _pbar(n2 - 1, np.array(min(1.0, max(-1.0, u[0]))))
@@ -409,8 +429,7 @@ def translation_SR(tr: Tree, n_end: int, k: float, t: np.ndarray) -> np.ndarray:
         return translation_SR_2d_graf(n_end, k, t)
     Cd = (2 * math.pi) ** (d / 2.0) * math.sqrt(2.0 / math.pi)
     n2 = 2 * n_end - 1
-    j, y, _, _ = radial(n2 - 1, d, k * r)
-    hn = j + 1j * y
+    _, hn, _, _ = radial_h(n2 - 1, d, k * r)
     u = t / r
     if tr.name == "ba":
         ent, tix, cf = _terms3(n_end)
@@ -561,8 +580,8 @@ def point_source(k: float, source, n: int):
     def _h(r, der=False):
         out = np.empty(r.shape, dtype=np.complex128)
         for i, ri in np.ndenumerate(r):
-            j, y, jp, yp = radial(n, d, k * ri)
-            out[i] = (jp[n] + 1j * yp[n]) if der else (j[n] + 1j * y[n])
+            _, h, _, hp = radial_h(n, d, k * ri)
+            out[i] = hp[n] if der else h[n]
         return out
 
     def u(x):
@@ -604,9 +623,7 @@ def ball_tables(tr: Tree, n_end: int, k: float, eta: float, rho: float, alpha: c
     blc = dlc - i eta slc,  slc = i k^{d-2} rho^{d-1} j_n, dlc = i k^{d-1} rho^{d-1} j_n'  (_biem.py:516-517,742)
     """
     d = tr.d
-    j, y, jp, yp = radial(n_end - 1, d, k * rho)
-    h = j + 1j * y
-    hp = jp + 1j * yp
+    j, h, jp, hp = radial_h(n_end - 1, d, k * rho)
     gj = alpha * j + beta * k * jp
     gh = alpha * h + beta * k * hp
     slc = 1j * k ** (d - 2) * rho ** (d - 1) * j
@@ -706,7 +723,7 @@ def uscat(res: OracleResult, x, far_field: bool = False, per_ball: bool = False)
         rs = np.where(r > 0, r, 1.0)
         Y = tr.harmonics(rel / rs[:, None], n_end)        # [H, P]
         # blc from the stored (k, eta, rho) -- density * SD_coef * Y  (_biem.py:896-917, 961)
-        j, _, jp, _ = radial(n_end - 1, d, k * res.radii[b])
+        j, _, jp, _ = radial_h(n_end - 1, d, k * res.radii[b])
         blc = 1j * k ** (d - 1) * res.radii[b] ** (d - 1) * jp - 1j * eta * (1j * k ** (d - 2) * res.radii[b] ** (d - 1) * j)
         c = res.density[b] * blc[deg]
         if far_field:
@@ -716,8 +733,8 @@ def uscat(res: OracleResult, x, far_field: bool = False, per_ball: bool = False)
         else:
             hn = np.empty((n_end, xs.shape[0]), dtype=np.complex128)
             for p, rp in enumerate(rs):
-                jj, yy, _, _ = radial(n_end - 1, d, k * rp)
-                hn[:, p] = jj + 1j * yy
+                _, hh, _, _ = radial_h(n_end - 1, d, k * rp)
+                hn[:, p] = hh
             out[:, b] = np.sum(c[:, None] * hn[deg, :] * Y, axis=0)
             if res.kind == "outer":
                 bad |= r < res.radii[b]

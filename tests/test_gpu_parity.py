@@ -37,6 +37,27 @@ def _dev(a, dtype=torch.float64):
 
 # ---------------------------------------------------------------------------- special functions
 @pytest.mark.parametrize("d", [2, 3, 4])
+def test_radial_complex_device_vs_scipy(lib, d):
+    """Complex arguments (complex wavenumber): regular z_n and outgoing h_n against SciPy's Amos routines, RELATIVE error -
+    h_n is computed directly, so it stays accurate where j and y are e^{2 Im z} times larger (parity unpinned by the
+    reference: no fixture has complex k; SciPy is the checker)."""
+    l, L = lib
+    nmax = 50
+    zs = np.array([0.3 + 0.1j, 1.3 + 0.25j, 1.9 + 1.0j, 2.5 + 0.01j, 5 + 3j, 12 + 0.5j, 20 + 8j, 40 + 0.2j, 3 - 0.4j, 0.05 + 0.02j,
+                   8 + 15j, 60 + 30j, 1e-3 + 1e-3j, 2.0 + 1e-9j, 7.0 + 0.0j])
+    z = _dev(zs, torch.complex128)
+    out = torch.zeros((len(zs), 2, nmax + 1), dtype=torch.complex128, device="cuda")
+    L.check(l.biem_radial_complex(d, nmax, len(zs), z.data_ptr(), out.data_ptr(), None))
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for i, zv in enumerate(zs):
+        j, h, _, _ = O.radial_h(nmax, d, zv if zv.imag != 0 else zv.real)
+        ok = np.isfinite(h) & (np.abs(h) < 1e290) & (np.abs(j) > 1e-290)
+        assert np.max(np.abs(out[i, 0][ok] / j[ok] - 1)) < 5e-12, (d, zv)
+        assert np.max(np.abs(out[i, 1][ok] / h[ok] - 1)) < 5e-12, (d, zv)
+
+
+@pytest.mark.parametrize("d", [2, 3, 4])
 def test_radial_device_vs_scipy(lib, d):
     l, L = lib
     nmax = 60
@@ -410,3 +431,47 @@ def test_factor_once_solve_many_incidences(amd, lib):
             ref = O.uscat(res, x)
             assert np.max(np.abs(u[:, r, s] - ref) / np.abs(ref)) < 1e-10, (r, s)
             assert np.max(np.abs(dens[r, s].cpu().numpy() - res.density)) < 1e-9 * np.abs(res.density).max()
+
+
+# ---------------------------------------------------------------------------- complex wavenumbers
+@pytest.mark.parametrize("tree, cen", [("a", [[0.0, 1.6], [0.3, -1.5], [2.9, 0.2]]), ("ba", [[0.0, 1.6, 0.2], [0.3, -1.5, 0.0], [2.9, 0.1, -0.4]]),
+                                       ("bba", [[0.0, 1.6, 0.2, 0.1], [0.3, -1.5, 0.0, 0.0]])])
+def test_complex_wavenumber_vs_oracle(amd, tree, cen):
+    """k with Im k > 0 (absorbing medium; the reference's GUI passes complex k, gui.py:296-301): Robin rows, batch of
+    complex and real k in one call, near field, far field and per-ball output against the oracle (SciPy complex Bessel)."""
+    c = amd.create_from_branching_types(tree)
+    cen = np.array(cen)
+    d = cen.shape[1]
+    rad = np.array([1.0, 0.8, 0.6])[: len(cen)]
+    ks = np.array([1.3 + 0.25j, 0.9 + 0.0j, 2.2 + 0.6j])
+    n_end = 9 if d < 4 else 7
+    dv = np.zeros(d); dv[0] = 0.6; dv[1] = 0.8
+    uin, ugr = amd.plane_wave(k=_dev(ks, torch.complex128), direction=_dev(np.repeat(dv[:, None], 3, 1)))
+    calc = amd.biem(c, centers=_dev(cen)[None], radii=_dev(rad)[None], k=_dev(ks, torch.complex128), n_end=n_end, alpha=1.0, beta=0.35,
+                    eta=_dev(np.array([1.0, 2.0, 0.5])), uin=uin, uin_grad=ugr)
+    assert calc.k.is_complex()
+    xs = np.array([[4.0, 0.5] + [0.2] * (d - 2), [-3.0, 2.0] + [0.1] * (d - 2), [0.7, -4.2] + [0.0] * (d - 2)])
+    u = calc.uscat(_dev(xs.T)).cpu().numpy()                               # [P, K]
+    uf = calc.uscat(_dev(xs.T), far_field=True).cpu().numpy()
+    upb = calc.uscat(_dev(xs.T), per_ball=True).cpu().numpy()              # [P, K, B]
+    assert np.max(np.abs(upb.sum(-1) - u)) < 1e-12 * np.abs(u).max()
+    for i, k in enumerate(ks):
+        kk = k if k.imag != 0 else k.real
+        uo, go = O.plane_wave(kk, dv)
+        res = O.solve_biem(tree, centers=cen, radii=rad, k=kk, n_end=n_end, alpha=1.0, beta=0.35, eta=[1.0, 2.0, 0.5][i], uin=uo, uin_grad=go)
+        ref, reff = O.uscat(res, xs), O.uscat(res, xs, far_field=True)
+        assert np.max(np.abs(u[:, i] - ref) / np.abs(ref)) < 1e-10, (tree, k)
+        assert np.max(np.abs(uf[:, i] - reff) / np.abs(reff)) < 1e-10, (tree, k)
+        dn = calc.density[i].cpu().numpy()
+        assert np.max(np.abs(dn - res.density)) < 1e-9 * np.abs(res.density).max(), (tree, k)
+
+
+def test_point_source_complex_wavenumber(amd):
+    k = 1.1 + 0.3j
+    src = np.array([0.2, -0.1, 3.0])
+    u, g = amd.point_source(k=_dev(np.array(k), torch.complex128), source=_dev(src), n=2)
+    uo, go = O.point_source(k, src, 2)
+    x = np.array([[1.0, 0.5, -0.2], [0.0, 2.0, 1.0], [-1.5, 0.3, 0.4]])
+    assert np.max(np.abs(u(_dev(x.T)).cpu().numpy() - uo(x)) / np.abs(uo(x))) < 1e-11
+    gg = g(_dev(x.T)).cpu().numpy().T
+    assert np.max(np.abs(gg - go(x))) < 1e-11 * np.abs(go(x)).max()

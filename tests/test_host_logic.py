@@ -71,8 +71,10 @@ def test_input_validation_messages():
         v(c, np.zeros((2, 2)), np.ones(2), np.asarray(1.0), None, 1.0, 0.0)
     with pytest.raises(TypeError):
         v(c, [[0, 0, 0]], np.ones(1), np.asarray(1.0), None, 1.0, 0.0)
-    with pytest.raises(NotImplementedError):
-        v(c, np.zeros((2, 3)), np.ones(2), np.asarray(1.0 + 0.1j), None, 1.0, 0.0)
+    # complex wavenumbers are accepted (reference gui.py:296-301); a complex decoupling parameter is not (:267-268)
+    assert v(c, np.zeros((2, 3)), np.ones(2), np.asarray(1.0 + 0.1j), None, 1.0, 0.0) == ()
+    with pytest.raises(ValueError, match="decoupling parameter must be real"):
+        v(c, np.zeros((2, 3)), np.ones(2), np.asarray(1.0), np.asarray(1.0 + 1.0j), 1.0, 0.0)
 
 
 def test_plane_wave_contract():
