@@ -7,9 +7,9 @@ Workload (BASELINE.json configs[2], the one the metric is quoted on; it fits one
     batch of wavenumbers k in [0.5, 8].
 One *step* = one pass of the whole hot path (boundary samples -> RHS projection -> fill -> LU -> density) over this
 rank's shard of the batch through the public `biem()` API; inputs are resident in HBM when the clock starts, the
-densities are resident in HBM when it stops.  Weak scaling: every GPU owns `--systems-per-gpu` systems (default 32,
-so 8 GPUs solve the 256-wavenumber batch of the config); the k's of the whole job are linspace(0.5, 8, 32*N), rank r
-takes the r-th contiguous block.  No collective sits in the data path (independent systems); RCCL is
+densities are resident in HBM when it stops.  Weak scaling: every GPU owns `--systems-per-gpu` systems (default 256 =
+the whole 256-wavenumber batch of the config, which fits one MI355X: 256 x 656 MB of matrices); the k's of the whole job
+are linspace(0.5, 8, 256*N), rank r takes the r-th contiguous block.  No collective sits in the data path (independent systems); RCCL is
 used only for the barrier / max-reduce of the timing.
 
 Prints ONE JSON line on rank 0 (fields per the driver contract, plus `roofline` and `cpu_baseline`).
@@ -69,9 +69,9 @@ def cpu_baseline(n_end: int, centers: np.ndarray, k: float):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--systems-per-gpu", type=int, default=32)
+    ap.add_argument("--systems-per-gpu", type=int, default=256)
     ap.add_argument("--n-end", type=int, default=20)
     ap.add_argument("--chunk", type=int, default=0, help="resident matrices per pass (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -626,12 +626,21 @@ def biem(
             L.check(lib.biem_density(plan.handle, nb, B, nrhs, _ptr(f), nrhs * B * H, 1, B * H, _ptr(tab), _ptr(density_t), sp),
                     "biem_density")
         elif has_rhs:
-            wbytes = int(lib.biem_solve_workspace_bytes(plan.handle, nb, B, nrhs, int(chunk)))
+            chunk = int(chunk)
+            if chunk <= 0:
+                # resident matrices per pass: as many as fit 85 % of the memory this process can still get (free + cached by
+                # torch's allocator).  The per-system kernels of the LU (panel strips, diagonal-block inverses, back
+                # substitution) are latency-bound on ONE CU per system, so they cost the same for 32 or 256 systems.
+                per = max(1, int(lib.biem_solve_workspace_bytes(plan.handle, 1, B, nrhs, 1)))
+                free, _total = torch.cuda.mem_get_info(dev)
+                avail = free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+                chunk = max(1, min(nb, int(0.85 * avail) // per))
+            wbytes = int(lib.biem_solve_workspace_bytes(plan.handle, nb, B, nrhs, chunk))
             work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
             density_t = torch.empty((nb, nrhs, B, H), dtype=torch.complex128, device=dev)
             info = torch.zeros(nb, dtype=torch.int32, device=dev)
             L.check(lib.biem_solve(plan.handle, nb, B, nrhs, _ptr(fl.k), _ptr(fl.eta), _ptr(fl.centers), _ptr(fl.radii), fl.geom_batched,
-                                   _ptr(fl.alpha), _ptr(fl.beta), fl.ab_batched, _ptr(g), _ptr(density_t), _ptr(info), int(chunk),
+                                   _ptr(fl.alpha), _ptr(fl.beta), fl.ab_batched, _ptr(g), _ptr(density_t), _ptr(info), chunk,
                                    _ptr(work), wbytes, sp), "biem_solve")
             del work
 
