@@ -634,7 +634,7 @@ def biem(
                 per = max(1, int(lib.biem_solve_workspace_bytes(plan.handle, 1, B, nrhs, 1)))
                 free, _total = torch.cuda.mem_get_info(dev)
                 avail = free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-                chunk = max(1, min(nb, int(0.85 * avail) // per))
+                chunk = max(1, min(nb, 32768, int(0.85 * avail) // per))      # 32768: grid dimension of the per-system kernels
             wbytes = int(lib.biem_solve_workspace_bytes(plan.handle, nb, B, nrhs, chunk))
             work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
             density_t = torch.empty((nb, nrhs, B, H), dtype=torch.complex128, device=dev)

@@ -189,6 +189,7 @@ SolveLayout make_layout(const biem_plan* p, int nb, int B, int nrhs, int chunk) 
     chunk = (int)(fit < 1 ? 1 : (fit > (size_t)nb ? (size_t)nb : fit));
   }
   if (chunk > nb) chunk = nb;
+  if (chunk > 32768) chunk = 32768;            // grid y / z dimensions of the per-system kernels
   L.chunk = chunk;
   size_t o = 0;
   L.off_tab = o; o = align256(o + (size_t)nb * B * 3 * p->n_end * 16);

@@ -851,18 +851,15 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
   if (nb <= 0 || n_pad <= 0) return BIEM_OK;
   if (n_pad % NB) { set_error("biem_lu: n_pad=%d is not a multiple of %d (use biem_lu_npad)", n_pad, NB); return BIEM_ERR_ARG; }
   if (nrhs < 0 || lda < n_pad + nrhs) { set_error("biem_lu: lda < n_pad + nrhs"); return BIEM_ERR_ARG; }
+  if (nb > 65535 || nrhs > 65535) { set_error("biem_lu: at most 65535 systems / right-hand sides per call (got %d / %d)", nb, nrhs); return BIEM_ERR_ARG; }
   if (work_bytes < lu_workspace_bytes(nb, n_pad, nrhs)) { set_error("biem_lu: workspace too small"); return BIEM_ERR_ARG; }
   cplx* A = (cplx*)d_A;
   cplx* Pw = (cplx*)d_work;
   const long long ldp = ldp_of(n_pad), p_stride = 2LL * NB * ldp;
   const int n_cols = n_pad + nrhs;
   hipLaunchKernelGGL(k_zero_int, dim3((nb + 63) / 64), dim3(64), 0, st, d_info, nb);
-  static bool inv_attr = false;
-  if (!inv_attr) {
-
-    BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_inv_l11, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * NB * NB * sizeof(cplx))));
-    inv_attr = true;
-  }
+  // (per call, not once per process: the attribute belongs to the current device)
+  BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_inv_l11, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * NB * NB * sizeof(cplx))));
 
   // factor the 64-column panel at column j, multipliers into P columns [pc, pc + NB)
   auto panel = [&](int j, int pc) {

@@ -475,3 +475,20 @@ def test_point_source_complex_wavenumber(amd):
     assert np.max(np.abs(u(_dev(x.T)).cpu().numpy() - uo(x)) / np.abs(uo(x))) < 1e-11
     gg = g(_dev(x.T)).cpu().numpy().T
     assert np.max(np.abs(gg - go(x))) < 1e-11 * np.abs(go(x)).max()
+
+
+def test_many_small_systems_are_chunked(amd):
+    """cfg 1 geometry, 40 000 wavenumbers in one call: more systems than a grid dimension holds, so the solve is split into
+    resident chunks; first, middle and last system against the oracle."""
+    c = amd.create_from_branching_types("ba")
+    cen = np.array([[0.0, 2.0, 0.0], [0.0, -2.0, 0.0]])
+    ks = np.linspace(0.5, 3.0, 40000)
+    dirs = np.zeros((3, len(ks))); dirs[0] = 1.0
+    uin, _ = amd.plane_wave(k=_dev(ks), direction=_dev(dirs))
+    calc = amd.biem(c, centers=_dev(cen)[None], radii=_dev(np.ones(2))[None], k=_dev(ks), n_end=6, uin=uin)
+    u = calc.uscat(_dev(np.zeros((3, 1)))).cpu().numpy()[0]
+    assert u.shape == (40000,) and np.all(np.isfinite(u))
+    for i in (0, 20000, 39999):
+        uo, _ = O.plane_wave(ks[i], [1.0, 0.0, 0.0])
+        res = O.solve_biem("ba", centers=cen, radii=np.ones(2), k=ks[i], n_end=6, uin=uo)
+        assert abs(u[i] - O.uscat(res, np.zeros((1, 3)))[0]) < 1e-11 * abs(u[i]), i
