@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int
   __shared__ cplx sH[kMaxRad * 2 + 6];
   int pair = blockIdx.x, s = blockIdx.y;
   int b = pair / B, bp = pair % B;
-  if (b == bp) return;
+  if (b >= bp) return;                       // the fill derives block (bp, b) from (b, bp)
   const double* cb = centers + ((geom_batched ? (size_t)s * B : 0) + b) * d;
   const double* cp = centers + ((geom_batched ? (size_t)s * B : 0) + bp) * d;
   double t[4];
@@ -189,21 +189,33 @@ __global__ void __launch_bounds__(FILL_THREADS) k_fill(int H, int H2, int n_end,
                                                         const cplx* __restrict__ tab, int scaling, cplx* __restrict__ A,
                                                         long long lda, long long sys_stride) {
   extern __shared__ char smem[];
-  cplx* sT = (cplx*)smem;                               // [H2]
-  cplx* sC = sT + H2;                                   // [H] column factors of the partner ball
-  double* sCoef = (double*)(sC + H);                    // [chunk_terms_max]
+  cplx* sT = (cplx*)smem;                               // [H2] pair table T_{b,bp}
+  cplx* sC = sT + H2;                                   // [H] column factors of the partner ball bp
+  cplx* sC2 = sC + H;                                   // [H] column factors of the owner ball b (mirrored block)
+  double* sCoef = (double*)(sC2 + H);                   // [chunk_terms_max]
   uint32_t* sPtr = (uint32_t*)(sCoef + chunk_terms_max);   // [chunk_ents_max + 1], relative to the chunk's first term
   uint16_t* sIdx = (uint16_t*)(sPtr + chunk_ents_max + 1);
-  const int chunk = blockIdx.x, b = blockIdx.y, s = blockIdx.z, tid = threadIdx.x;
+  const int chunk = blockIdx.x, s = blockIdx.z, tid = threadIdx.x;
   const int e0 = chunk_ent[chunk], e1 = chunk_ent[chunk + 1], nent = e1 - e0;
   const uint32_t t0 = ptr[e0], t1 = ptr[e1];
   for (uint32_t q = t0 + tid; q < t1; q += FILL_THREADS) { sCoef[q - t0] = coef[q]; sIdx[q - t0] = tidx[q]; }
   for (int e = tid; e <= nent; e += FILL_THREADS) sPtr[e] = ptr[e0 + e] - t0;
-  const cplx* tb = tab + ((size_t)s * B + b) * 3 * n_end;
-  cplx* Arow = A + (size_t)s * sys_stride + ((size_t)b * H) * lda;
-  for (int bp = 0; bp < B; ++bp) {
-    cplx* Ab = Arow + (size_t)bp * H;
-    if (bp == b) {
+  cplx* As = A + (size_t)s * sys_stride;
+  auto colfac = [&](const cplx* tball, int hp) {        // column factor of a ball for harmonic hp
+    const int n = deg[hp];
+    return scaling == BIEM_FILL_REFERENCE ? tball[2 * n_end + n] : crecip(tball[n_end + n]);
+  };
+  // the raw sum of an entry is shared by the two blocks of an unordered pair: T_{bp,b}[l] = (-1)^{n''} T_{b,bp}[l] (harmonics of
+  // degree n'' at -t) and every term of entry (h, h') has n'' = n + n' (mod 2), so S_{bp,b}[h,h'] = (-1)^{n+n'} S_{b,bp}[h,h'].
+  // A workgroup owns balls b1 = blockIdx.y and b2 = B-1-b1 and contracts each with its partners bp > b: B-1 contractions per
+  // workgroup whatever b1 is, half the contractions of the one-block-per-contraction form.
+  const int b1 = blockIdx.y, b2 = B - 1 - b1;
+  for (int own = 0; own < 2; ++own) {
+    const int b = own == 0 ? b1 : b2;
+    if (own == 1 && b2 == b1) break;
+    const cplx* tb = tab + ((size_t)s * B + b) * 3 * n_end;
+    {  // diagonal block of b
+      cplx* Ab = As + ((size_t)b * H) * lda + (size_t)b * H;
       for (int e = tid; e < nent; e += FILL_THREADS) {
         int h = (e0 + e) / H, hp = (e0 + e) - h * H;
         cplx v = make_double2(0.0, 0.0);
@@ -213,45 +225,49 @@ __global__ void __launch_bounds__(FILL_THREADS) k_fill(int H, int H2, int n_end,
         }
         Ab[(size_t)h * lda + hp] = v;
       }
-      continue;
     }
-    const cplx* tbp = tab + ((size_t)s * B + bp) * 3 * n_end;
-    const cplx* Tp = T + ((size_t)s * B * B + (size_t)b * B + bp) * H2;
-    __syncthreads();                                     // previous partner's table no longer in use (also orders the chunk loads)
-    for (int l = tid; l < H2; l += FILL_THREADS) sT[l] = Tp[l];
-    for (int hp = tid; hp < H; hp += FILL_THREADS) {
-      int n = deg[hp];
-      sC[hp] = scaling == BIEM_FILL_REFERENCE ? tbp[2 * n_end + n] : crecip(tbp[n_end + n]);
-    }
-    __syncthreads();
-    for (int e = tid; e < nent; e += 2 * FILL_THREADS) {
-      const int eb = e + FILL_THREADS;
-      const bool two = eb < nent;
-      uint32_t p0 = sPtr[e], p1 = sPtr[e + 1];
-      uint32_t q0 = two ? sPtr[eb] : 0, q1 = two ? sPtr[eb + 1] : 0;
-      double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
-      while (p0 < p1 && q0 < q1) {                       // two independent chains
-        double c = sCoef[p0], d = sCoef[q0];
-        cplx t = sT[sIdx[p0]], u = sT[sIdx[q0]];
-        ar = fma(c, t.x, ar); ai = fma(c, t.y, ai);
-        br = fma(d, u.x, br); bi = fma(d, u.y, bi);
-        ++p0; ++q0;
-      }
-      for (; p0 < p1; ++p0) { double c = sCoef[p0]; cplx t = sT[sIdx[p0]]; ar = fma(c, t.x, ar); ai = fma(c, t.y, ai); }
-      for (; q0 < q1; ++q0) { double d = sCoef[q0]; cplx u = sT[sIdx[q0]]; br = fma(d, u.x, br); bi = fma(d, u.y, bi); }
-      {
-        int h = (e0 + e) / H, hp = (e0 + e) - h * H;
-        Ab[(size_t)h * lda + hp] = cmul(cmul(make_double2(ar, ai), tb[deg[h]]), sC[hp]);
-      }
-      if (two) {
-        int h = (e0 + eb) / H, hp = (e0 + eb) - h * H;
-        Ab[(size_t)h * lda + hp] = cmul(cmul(make_double2(br, bi), tb[deg[h]]), sC[hp]);
+    if (b + 1 >= B) continue;
+    __syncthreads();                                     // previous owner's sC2 no longer in use (also orders the chunk loads)
+    for (int hp = tid; hp < H; hp += FILL_THREADS) sC2[hp] = colfac(tb, hp);
+    for (int bp = b + 1; bp < B; ++bp) {
+      const cplx* tbp = tab + ((size_t)s * B + bp) * 3 * n_end;
+      const cplx* Tp = T + ((size_t)s * B * B + (size_t)b * B + bp) * H2;
+      cplx* Ab = As + ((size_t)b * H) * lda + (size_t)bp * H;     // block (b, bp)
+      cplx* Am = As + ((size_t)bp * H) * lda + (size_t)b * H;     // block (bp, b)
+      __syncthreads();                                   // previous partner's table no longer in use
+      for (int l = tid; l < H2; l += FILL_THREADS) sT[l] = Tp[l];
+      for (int hp = tid; hp < H; hp += FILL_THREADS) sC[hp] = colfac(tbp, hp);
+      __syncthreads();
+      auto put = [&](int e, double sr, double si) {
+        const int h = (e0 + e) / H, hp = (e0 + e) - h * H;
+        const int nh = deg[h];
+        const cplx raw = make_double2(sr, si);
+        Ab[(size_t)h * lda + hp] = cmul(cmul(raw, tb[nh]), sC[hp]);
+        const cplx m = cmul(cmul(raw, tbp[nh]), sC2[hp]);
+        Am[(size_t)h * lda + hp] = ((nh + deg[hp]) & 1) ? make_double2(-m.x, -m.y) : m;
+      };
+      for (int e = tid; e < nent; e += 2 * FILL_THREADS) {
+        const int eb = e + FILL_THREADS;
+        const bool two = eb < nent;
+        uint32_t p0 = sPtr[e], p1 = sPtr[e + 1];
+        uint32_t q0 = two ? sPtr[eb] : 0, q1 = two ? sPtr[eb + 1] : 0;
+        double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
+        while (p0 < p1 && q0 < q1) {                     // two independent chains
+          double c = sCoef[p0], d = sCoef[q0];
+          cplx t = sT[sIdx[p0]], u = sT[sIdx[q0]];
+          ar = fma(c, t.x, ar); ai = fma(c, t.y, ai);
+          br = fma(d, u.x, br); bi = fma(d, u.y, bi);
+          ++p0; ++q0;
+        }
+        for (; p0 < p1; ++p0) { double c = sCoef[p0]; cplx t = sT[sIdx[p0]]; ar = fma(c, t.x, ar); ai = fma(c, t.y, ai); }
+        for (; q0 < q1; ++q0) { double d = sCoef[q0]; cplx u = sT[sIdx[q0]]; br = fma(d, u.x, br); bi = fma(d, u.y, bi); }
+        put(e, ar, ai);
+        if (two) put(eb, br, bi);
       }
     }
   }
 }
 
-// identity padding: rows/cols N..n_pad-1
 __global__ void k_fill_pad(int N, int n_pad, cplx* __restrict__ A, long long lda, long long sys_stride) {
   int s = blockIdx.y;
   cplx* As = A + (size_t)s * sys_stride;
@@ -284,14 +300,14 @@ int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const doub
                        p->d_deg2, B, (const cplx*)d_k, d_centers, geom_batched, T);
     BIEM_LAUNCHCHK();
   }
-  size_t shm = (size_t)(p->H2 + H) * sizeof(cplx) + (size_t)p->chunk_terms_max * 10 + (size_t)(p->chunk_ents_max + 1) * 4 + 16;
+  size_t shm = (size_t)(p->H2 + 2 * H) * sizeof(cplx) + (size_t)p->chunk_terms_max * 10 + (size_t)(p->chunk_ents_max + 1) * 4 + 16;
   if (shm > 160 * 1024 || p->chunk_terms_max == 0 && p->coef.size() > 0) {
     set_error("biem_fill: tables do not fit LDS (H2=%d, chunk terms=%d)", p->H2, p->chunk_terms_max);
     return BIEM_ERR_UNSUPPORTED;
   }
   BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   const int nchunks = (int)p->chunk_ent.size() - 1;
-  hipLaunchKernelGGL(k_fill, dim3(nchunks, B, nb), dim3(FILL_THREADS), shm, st, H, p->H2, p->n_end, B, p->d_deg, p->d_chunk_ent,
+  hipLaunchKernelGGL(k_fill, dim3(nchunks, (B + 1) / 2, nb), dim3(FILL_THREADS), shm, st, H, p->H2, p->n_end, B, p->d_deg, p->d_chunk_ent,
                      p->chunk_terms_max, p->chunk_ents_max, p->d_ptr, p->d_coef, p->d_tidx16, T, (const cplx*)d_tab, scaling,
                      (cplx*)d_A, lda, sys_stride);
   BIEM_LAUNCHCHK();
