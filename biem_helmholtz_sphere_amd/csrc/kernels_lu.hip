@@ -368,7 +368,6 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
   __shared__ cplx ring[3 * STG];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA bases (M0) and tile offsets stay on the SALU
-  const int wm = wave >> 1, wn = wave & 1;
   const int l3 = lane & 3, l15 = lane & 15, l4 = lane >> 4;
   const int w = blockIdx.x, nblk = gridDim.x >> 3, xl = w & 7;
   int q = (w >> 3) - nblk;
@@ -393,7 +392,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
   const unsigned offA1 = (unsigned)(((size_t)(wave + 4) * ldp + lane) * sizeof(cplx));
   const unsigned offB0 = (unsigned)(((size_t)(wave) * lda + lane) * sizeof(cplx));
   const unsigned offB1 = (unsigned)(((size_t)(wave + 4) * lda + lane) * sizeof(cplx));
-  const unsigned offC = (unsigned)(((size_t)(wm * 32 + l4) * lda + wn * 32 + l15) * sizeof(cplx));
+  // wave w owns rows 16w .. 16w+15 of the 64 x 64 tile and all 64 columns: 4 broadcast A fragments (row quads g) and 4 B
+  // fragments (column groups n) per k4-step instead of the 8 + 2 of a 32 x 32 wave tile: 16 instead of 20 fragment reads
+  // and 3M operand sums per chunk.  C unit u = 4 n + g: rows 16w + 4g + (lane >> 4), columns 16n + (lane & 15).
+  const unsigned offC = (unsigned)(((size_t)(wave * 16 + l4) * lda + l15) * sizeof(cplx));
   // Producer state: the DMA stream runs two chunks ahead of the multiplication and crosses tile boundaries on its own.
   // Interior tiles use running scalar bases (pA, pB advance by a constant per chunk; pC = tile origin + a 16-entry
   // pattern); edge tiles recompute clamped per-lane addresses (rare).
@@ -424,7 +426,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
 #pragma unroll
       for (int i = 0; i < UPC; ++i) {
         const int u = p_ch * UPC + i;
-        const long long dC = ((long long)((u >> 3) * 16 + 4 * (u & 3)) * lda + ((u >> 2) & 1) * 16) * (long long)sizeof(cplx);
+        const long long dC = ((long long)(4 * (u & 3)) * lda + (u >> 2) * 16) * (long long)sizeof(cplx);
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(pC + dC + offC), (lds_ptr_t)(S + COF + i * 256 + wave * 64), 16, 0, 0);
       }
     } else {
@@ -444,8 +446,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
 #pragma unroll
       for (int i = 0; i < UPC; ++i) {
         const int u = p_ch * UPC + i;
-        const int row = min(r0 + wm * 32 + (u >> 3) * 16 + 4 * (u & 3) + l4, n_pad - 1);
-        const int col = min(c0 + wn * 32 + ((u >> 2) & 1) * 16 + l15, n_cols - 1);
+        const int row = min(r0 + wave * 16 + 4 * (u & 3) + l4, n_pad - 1);
+        const int col = min(c0 + (u >> 2) * 16 + l15, n_cols - 1);
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(As + (size_t)row * lda + col),
                                          (lds_ptr_t)(S + COF + i * 256 + wave * 64), 16, 0, 0);
       }
@@ -460,13 +462,11 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
     }
   };
 
-  double N1[2][2][4], P2[2][2][4], N3[2][2][4];
+  double N1[4][4], P2[4][4], N3[4][4];       // [column group n][row quad g]; flat index = C unit u = 4 n + g
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int n = 0; n < 4; ++n)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) { N1[a][b][g] = 0.0; P2[a][b][g] = 0.0; N3[a][b][g] = 0.0; }
+    for (int g = 0; g < 4; ++g) { N1[n][g] = 0.0; P2[n][g] = 0.0; N3[n][g] = 0.0; }
 
 #ifdef BIEM_TR_STAMPS
   __shared__ unsigned long long s_tr[4 * 64 * 8];
@@ -480,8 +480,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
   int st = 0;                 // stage of the chunk about to be multiplied
   int stores_pending = 0;     // 0: none, 1: 16 stores of a full tile were issued after the groups in flight, 2: unknown count
   // per-lane LDS offsets of the fragments inside a stage (elements)
-  const int fbo = BOF + l4 * 64 + wn * 32 + l15;          // + k4*4*64 + n*16
-  const int fao = l4 * AST + wm * 32 + l3;                // + k4*4*AST + tm*16 + 4g
+  const int fbo = BOF + l4 * 64 + l15;                    // + k4*4*64 + n*16
+  const int fao = l4 * AST + wave * 16 + l3;              // + k4*4*AST + 4g
   // A VALU instruction issued while the SIMD partner (the other workgroup's wave) streams MFMAs costs ~28 cycles even at
   // priority 3 (tools/mfma_valu_mix: 8 alone, 101 at equal priority; SALU and LDS instructions are unaffected).  So the
   // phase between two MFMA blocks holds no VALU work at all: the fragment addresses of the NEXT chunk, the 3M operand sums
@@ -529,22 +529,21 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
       const cplx* S = ring + st * STG;
       // fragments of both k4-steps and the C units of this chunk: 20 + UPC ds_read_b128 and their lgkmcnt wait in ONE asm
       // statement - hipcc may copy an asm output right after the statement, i.e. before a separate wait (that was the
-      // cause of percent-level errors in an earlier build); byte offsets: k4*4352 + tm*256 + g*64 (A), k4*4096 + n*256 (B)
-      cplx fb[2][2], fa[2][2][4], cv[UPC];
+      // cause of percent-level errors in an earlier build); byte offsets: k4*4352 + g*64 (A), k4*4096 + n*256 (B)
+      cplx fb[2][4], fa[2][4], cv[UPC];   // [k4][column group of 16], [k4][row quad]
       {
         if (UPC == 1 && fused) {
           typedef __attribute__((address_space(3))) cplx* lds_cplx_t;
           cplx* S2 = ring + st2 * STG;
           const unsigned mA = (unsigned)(size_t)(lds_cplx_t)(S2 + wave * AST), mB = (unsigned)(size_t)(lds_cplx_t)(S2 + BOF + wave * 64);
-          const long long dC = ((long long)((p_ch >> 3) * 16 + 4 * (p_ch & 3)) * lda + ((p_ch >> 2) & 1) * 16) * (long long)sizeof(cplx);
+          const long long dC = ((long long)(4 * (p_ch & 3)) * lda + (p_ch >> 2) * 16) * (long long)sizeof(cplx);
           const char* pCc = pC + dC;
           asm volatile(
 #ifndef BIEM_ABL_NOLDS
-              "ds_read_b128 %[b0], %[aB]\n\tds_read_b128 %[b1], %[aB] offset:256\n\tds_read_b128 %[b2], %[aB] offset:4096\n\tds_read_b128 %[b3], %[aB] offset:4352\n\t"
+              "ds_read_b128 %[b0], %[aB]\n\tds_read_b128 %[b1], %[aB] offset:256\n\tds_read_b128 %[b2], %[aB] offset:512\n\tds_read_b128 %[b3], %[aB] offset:768\n\t"
+              "ds_read_b128 %[b4], %[aB] offset:4096\n\tds_read_b128 %[b5], %[aB] offset:4352\n\tds_read_b128 %[b6], %[aB] offset:4608\n\tds_read_b128 %[b7], %[aB] offset:4864\n\t"
               "ds_read_b128 %[a0], %[aA]\n\tds_read_b128 %[a1], %[aA] offset:64\n\tds_read_b128 %[a2], %[aA] offset:128\n\tds_read_b128 %[a3], %[aA] offset:192\n\t"
-              "ds_read_b128 %[a4], %[aA] offset:256\n\tds_read_b128 %[a5], %[aA] offset:320\n\tds_read_b128 %[a6], %[aA] offset:384\n\tds_read_b128 %[a7], %[aA] offset:448\n\t"
-              "ds_read_b128 %[a8], %[aA] offset:4352\n\tds_read_b128 %[a9], %[aA] offset:4416\n\tds_read_b128 %[a10], %[aA] offset:4480\n\tds_read_b128 %[a11], %[aA] offset:4544\n\t"
-              "ds_read_b128 %[a12], %[aA] offset:4608\n\tds_read_b128 %[a13], %[aA] offset:4672\n\tds_read_b128 %[a14], %[aA] offset:4736\n\tds_read_b128 %[a15], %[aA] offset:4800\n\t"
+              "ds_read_b128 %[a4], %[aA] offset:4352\n\tds_read_b128 %[a5], %[aA] offset:4416\n\tds_read_b128 %[a6], %[aA] offset:4480\n\tds_read_b128 %[a7], %[aA] offset:4544\n\t"
               "ds_read_b128 %[c0], %[aC]\n\t"
 #endif
 #ifndef BIEM_ABL_ONLYCDMA
@@ -557,10 +556,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
               "s_add_u32 m0, %[mB], 8192\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oC], %[pC]\n\t"
 #endif
               "s_waitcnt lgkmcnt(0)"
-              : [a0] "=&v"(fa[0][0][0]), [a1] "=&v"(fa[0][0][1]), [a2] "=&v"(fa[0][0][2]), [a3] "=&v"(fa[0][0][3]), [a4] "=&v"(fa[0][1][0]),
-                [a5] "=&v"(fa[0][1][1]), [a6] "=&v"(fa[0][1][2]), [a7] "=&v"(fa[0][1][3]), [a8] "=&v"(fa[1][0][0]), [a9] "=&v"(fa[1][0][1]),
-                [a10] "=&v"(fa[1][0][2]), [a11] "=&v"(fa[1][0][3]), [a12] "=&v"(fa[1][1][0]), [a13] "=&v"(fa[1][1][1]), [a14] "=&v"(fa[1][1][2]),
-                [a15] "=&v"(fa[1][1][3]), [b0] "=&v"(fb[0][0]), [b1] "=&v"(fb[0][1]), [b2] "=&v"(fb[1][0]), [b3] "=&v"(fb[1][1]), [c0] "=&v"(cv[0])
+              : [a0] "=&v"(fa[0][0]), [a1] "=&v"(fa[0][1]), [a2] "=&v"(fa[0][2]), [a3] "=&v"(fa[0][3]), [a4] "=&v"(fa[1][0]),
+                [a5] "=&v"(fa[1][1]), [a6] "=&v"(fa[1][2]), [a7] "=&v"(fa[1][3]), [b0] "=&v"(fb[0][0]), [b1] "=&v"(fb[0][1]),
+                [b2] "=&v"(fb[0][2]), [b3] "=&v"(fb[0][3]), [b4] "=&v"(fb[1][0]), [b5] "=&v"(fb[1][1]), [b6] "=&v"(fb[1][2]),
+                [b7] "=&v"(fb[1][3]), [c0] "=&v"(cv[0])
               : [aA] "v"(aA), [aB] "v"(aB), [aC] "v"(aC), [mA] "s"(mA), [mB] "s"(mB), [oA0] "v"(offA0), [oA1] "v"(offA1), [oB0] "v"(offB0),
                 [oB1] "v"(offB1), [oC] "v"(offC), [pA] "s"(pA), [pB] "s"(pB), [pC] "s"(pCc)
               : "memory", "m0", "scc");
@@ -568,33 +567,31 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
           advance();
         } else if constexpr (UPC == 1) {
           asm volatile(
-              "ds_read_b128 %16, %22\n\tds_read_b128 %17, %22 offset:256\n\tds_read_b128 %18, %22 offset:4096\n\tds_read_b128 %19, %22 offset:4352\n\t"
-              "ds_read_b128 %0, %21\n\tds_read_b128 %1, %21 offset:64\n\tds_read_b128 %2, %21 offset:128\n\tds_read_b128 %3, %21 offset:192\n\t"
-              "ds_read_b128 %4, %21 offset:256\n\tds_read_b128 %5, %21 offset:320\n\tds_read_b128 %6, %21 offset:384\n\tds_read_b128 %7, %21 offset:448\n\t"
-              "ds_read_b128 %8, %21 offset:4352\n\tds_read_b128 %9, %21 offset:4416\n\tds_read_b128 %10, %21 offset:4480\n\tds_read_b128 %11, %21 offset:4544\n\t"
-              "ds_read_b128 %12, %21 offset:4608\n\tds_read_b128 %13, %21 offset:4672\n\tds_read_b128 %14, %21 offset:4736\n\tds_read_b128 %15, %21 offset:4800\n\t"
-              "ds_read_b128 %20, %23\n\t"
+              "ds_read_b128 %[b0], %[aB]\n\tds_read_b128 %[b1], %[aB] offset:256\n\tds_read_b128 %[b2], %[aB] offset:512\n\tds_read_b128 %[b3], %[aB] offset:768\n\t"
+              "ds_read_b128 %[b4], %[aB] offset:4096\n\tds_read_b128 %[b5], %[aB] offset:4352\n\tds_read_b128 %[b6], %[aB] offset:4608\n\tds_read_b128 %[b7], %[aB] offset:4864\n\t"
+              "ds_read_b128 %[a0], %[aA]\n\tds_read_b128 %[a1], %[aA] offset:64\n\tds_read_b128 %[a2], %[aA] offset:128\n\tds_read_b128 %[a3], %[aA] offset:192\n\t"
+              "ds_read_b128 %[a4], %[aA] offset:4352\n\tds_read_b128 %[a5], %[aA] offset:4416\n\tds_read_b128 %[a6], %[aA] offset:4480\n\tds_read_b128 %[a7], %[aA] offset:4544\n\t"
+              "ds_read_b128 %[c0], %[aC]\n\t"
               "s_waitcnt lgkmcnt(0)"
-              : "=&v"(fa[0][0][0]), "=&v"(fa[0][0][1]), "=&v"(fa[0][0][2]), "=&v"(fa[0][0][3]), "=&v"(fa[0][1][0]), "=&v"(fa[0][1][1]),
-                "=&v"(fa[0][1][2]), "=&v"(fa[0][1][3]), "=&v"(fa[1][0][0]), "=&v"(fa[1][0][1]), "=&v"(fa[1][0][2]), "=&v"(fa[1][0][3]),
-                "=&v"(fa[1][1][0]), "=&v"(fa[1][1][1]), "=&v"(fa[1][1][2]), "=&v"(fa[1][1][3]), "=&v"(fb[0][0]), "=&v"(fb[0][1]),
-                "=&v"(fb[1][0]), "=&v"(fb[1][1]), "=&v"(cv[0])
-              : "v"(aA), "v"(aB), "v"(aC)
+              : [a0] "=&v"(fa[0][0]), [a1] "=&v"(fa[0][1]), [a2] "=&v"(fa[0][2]), [a3] "=&v"(fa[0][3]), [a4] "=&v"(fa[1][0]),
+                [a5] "=&v"(fa[1][1]), [a6] "=&v"(fa[1][2]), [a7] "=&v"(fa[1][3]), [b0] "=&v"(fb[0][0]), [b1] "=&v"(fb[0][1]),
+                [b2] "=&v"(fb[0][2]), [b3] "=&v"(fb[0][3]), [b4] "=&v"(fb[1][0]), [b5] "=&v"(fb[1][1]), [b6] "=&v"(fb[1][2]),
+                [b7] "=&v"(fb[1][3]), [c0] "=&v"(cv[0])
+              : [aA] "v"(aA), [aB] "v"(aB), [aC] "v"(aC)
               : "memory");
         } else {
           asm volatile(
-              "ds_read_b128 %16, %23\n\tds_read_b128 %17, %23 offset:256\n\tds_read_b128 %18, %23 offset:4096\n\tds_read_b128 %19, %23 offset:4352\n\t"
-              "ds_read_b128 %0, %22\n\tds_read_b128 %1, %22 offset:64\n\tds_read_b128 %2, %22 offset:128\n\tds_read_b128 %3, %22 offset:192\n\t"
-              "ds_read_b128 %4, %22 offset:256\n\tds_read_b128 %5, %22 offset:320\n\tds_read_b128 %6, %22 offset:384\n\tds_read_b128 %7, %22 offset:448\n\t"
-              "ds_read_b128 %8, %22 offset:4352\n\tds_read_b128 %9, %22 offset:4416\n\tds_read_b128 %10, %22 offset:4480\n\tds_read_b128 %11, %22 offset:4544\n\t"
-              "ds_read_b128 %12, %22 offset:4608\n\tds_read_b128 %13, %22 offset:4672\n\tds_read_b128 %14, %22 offset:4736\n\tds_read_b128 %15, %22 offset:4800\n\t"
-              "ds_read_b128 %20, %24\n\tds_read_b128 %21, %24 offset:4096\n\t"
+              "ds_read_b128 %[b0], %[aB]\n\tds_read_b128 %[b1], %[aB] offset:256\n\tds_read_b128 %[b2], %[aB] offset:512\n\tds_read_b128 %[b3], %[aB] offset:768\n\t"
+              "ds_read_b128 %[b4], %[aB] offset:4096\n\tds_read_b128 %[b5], %[aB] offset:4352\n\tds_read_b128 %[b6], %[aB] offset:4608\n\tds_read_b128 %[b7], %[aB] offset:4864\n\t"
+              "ds_read_b128 %[a0], %[aA]\n\tds_read_b128 %[a1], %[aA] offset:64\n\tds_read_b128 %[a2], %[aA] offset:128\n\tds_read_b128 %[a3], %[aA] offset:192\n\t"
+              "ds_read_b128 %[a4], %[aA] offset:4352\n\tds_read_b128 %[a5], %[aA] offset:4416\n\tds_read_b128 %[a6], %[aA] offset:4480\n\tds_read_b128 %[a7], %[aA] offset:4544\n\t"
+              "ds_read_b128 %[c0], %[aC]\n\tds_read_b128 %[c1], %[aC] offset:4096\n\t"
               "s_waitcnt lgkmcnt(0)"
-              : "=&v"(fa[0][0][0]), "=&v"(fa[0][0][1]), "=&v"(fa[0][0][2]), "=&v"(fa[0][0][3]), "=&v"(fa[0][1][0]), "=&v"(fa[0][1][1]),
-                "=&v"(fa[0][1][2]), "=&v"(fa[0][1][3]), "=&v"(fa[1][0][0]), "=&v"(fa[1][0][1]), "=&v"(fa[1][0][2]), "=&v"(fa[1][0][3]),
-                "=&v"(fa[1][1][0]), "=&v"(fa[1][1][1]), "=&v"(fa[1][1][2]), "=&v"(fa[1][1][3]), "=&v"(fb[0][0]), "=&v"(fb[0][1]),
-                "=&v"(fb[1][0]), "=&v"(fb[1][1]), "=&v"(cv[0]), "=&v"(cv[UPC - 1])
-              : "v"(aA), "v"(aB), "v"(aC)
+              : [a0] "=&v"(fa[0][0]), [a1] "=&v"(fa[0][1]), [a2] "=&v"(fa[0][2]), [a3] "=&v"(fa[0][3]), [a4] "=&v"(fa[1][0]),
+                [a5] "=&v"(fa[1][1]), [a6] "=&v"(fa[1][2]), [a7] "=&v"(fa[1][3]), [b0] "=&v"(fb[0][0]), [b1] "=&v"(fb[0][1]),
+                [b2] "=&v"(fb[0][2]), [b3] "=&v"(fb[0][3]), [b4] "=&v"(fb[1][0]), [b5] "=&v"(fb[1][1]), [b6] "=&v"(fb[1][2]),
+                [b7] "=&v"(fb[1][3]), [c0] "=&v"(cv[0]), [c1] "=&v"(cv[UPC - 1])
+              : [aA] "v"(aA), [aB] "v"(aB), [aC] "v"(aC)
               : "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -603,26 +600,22 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
       // 3M operand sums and the C-slice additions BEFORE the MFMA block (measured: issued inside the block, in the shadow of
       // this wave's own MFMAs, the FP64 adds cost more - they share the FP64 pipe with the MFMAs and the C additions then
       // wait for accumulators in flight: 57.6 vs 63.1 TFLOP/s; only the integer address work below is free in there).
-      double fbs[2][2], fas[2][2][4];
+      double fbs[2][4], fas[2][4];
 #pragma unroll
       for (int k4 = 0; k4 < 2; ++k4) {
 #ifdef BIEM_ABL_NOSUMS
 #pragma unroll
-        for (int n = 0; n < 2; ++n) fbs[k4][n] = fb[k4][n].x;
+        for (int n = 0; n < 4; ++n) fbs[k4][n] = fb[k4][n].x;
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) fas[k4][tm][g] = fa[k4][tm][g].x;
+        for (int g = 0; g < 4; ++g) fas[k4][g] = fa[k4][g].x;
 #else
 #pragma unroll
-        for (int n = 0; n < 2; ++n) fbs[k4][n] = fb[k4][n].x + fb[k4][n].y;
+        for (int n = 0; n < 4; ++n) fbs[k4][n] = fb[k4][n].x + fb[k4][n].y;
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) fas[k4][tm][g] = fa[k4][tm][g].x + fa[k4][tm][g].y;
+        for (int g = 0; g < 4; ++g) fas[k4][g] = fa[k4][g].x + fa[k4][g].y;
 #endif
       }
-      // this chunk's C units (u = c*UPC + i -> sub-tile (u>>3, (u>>2)&1), register u&3) join their accumulators.  Which
+      // this chunk's C units (u = c*UPC + i -> column group u>>2, row quad u&3) join their accumulators.  Which
       // accumulator that is depends on c: a switch over c made hipcc merge all 32 accumulators through v_mov_b64 copies
       // behind the MFMA block (~1300 stalled cycles per chunk, found with tools/gemm_trace), an fma(value, sel_u, acc_u) over
       // all units cost 32 FP64 VALU instructions that compete with the MFMAs for the FP64 pipe.  A dynamically indexed
@@ -630,8 +623,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
 #ifndef BIEM_ABL_NOCADD
 #pragma unroll
       for (int i = 0; i < UPC; ++i) {
-        (&N1[0][0][0])[c * UPC + i] += cv[i].x;
-        (&N3[0][0][0])[c * UPC + i] += cv[i].x + cv[i].y;
+        (&N1[0][0])[c * UPC + i] += cv[i].x;
+        (&N3[0][0])[c * UPC + i] += cv[i].x + cv[i].y;
       }
 #endif
       // the MFMA block runs at low priority, everything else at high (the partner's SALU / LDS / VMEM phase slips between
@@ -650,30 +643,26 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
 #ifdef BIEM_ABL_NOMFMA     // timing ablation: data movement only
 #pragma unroll
       for (int k4 = 0; k4 < 2; ++k4) {
-        asm volatile("" ::"v"(fb[k4][0].x), "v"(fb[k4][0].y), "v"(fb[k4][1].x), "v"(fb[k4][1].y), "v"(fbs[k4][0]), "v"(fbs[k4][1]));
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        for (int n = 0; n < 4; ++n) asm volatile("" ::"v"(fb[k4][n].x), "v"(fb[k4][n].y), "v"(fbs[k4][n]));
 #pragma unroll
-          for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(fa[k4][tm][g].x), "v"(fa[k4][tm][g].y), "v"(fas[k4][tm][g]));
+        for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(fa[k4][g].x), "v"(fa[k4][g].y), "v"(fas[k4][g]));
       }
 #else
 #pragma unroll
       for (int k4 = 0; k4 < 2; ++k4) {
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
-          for (int n = 0; n < 2; ++n)
+          for (int g = 0; g < 4; ++g) mfma_acc_neg(N1[n][g], fa[k4][g].x, fb[k4][n].x);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) mfma_acc_neg(N1[tm][n][g], fa[k4][tm][g].x, fb[k4][n].x);
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
-          for (int n = 0; n < 2; ++n)
+          for (int g = 0; g < 4; ++g) mfma_acc(P2[n][g], fa[k4][g].y, fb[k4][n].y);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) mfma_acc(P2[tm][n][g], fa[k4][tm][g].y, fb[k4][n].y);
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
-          for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) mfma_acc_neg(N3[tm][n][g], fas[k4][tm][g], fbs[k4][n]);
-        }
+          for (int g = 0; g < 4; ++g) mfma_acc_neg(N3[n][g], fas[k4][g], fbs[k4][n]);
       }
 #endif
       mfma_fence();
@@ -695,35 +684,35 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
     if (full) {
       char* tb = (char*)(Cs + (size_t)row0 * lda + col0);
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
+      for (int n = 0; n < 4; ++n) {
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const long long du = ((long long)(tm * 16 + 4 * g) * lda + n * 16) * (long long)sizeof(cplx);
+        for (int g = 0; g < 4; ++g) {
+          const long long du = ((long long)(4 * g) * lda + n * 16) * (long long)sizeof(cplx);
 #ifdef BIEM_ABL_NOEPI
-            asm volatile("" ::"v"(N1[tm][n][g]), "v"(P2[tm][n][g]), "v"(N3[tm][n][g]));   // keep the MFMAs alive
+          asm volatile("" ::"v"(N1[n][g]), "v"(P2[n][g]), "v"(N3[n][g]));   // keep the MFMAs alive
+#elif defined(BIEM_ABL_ONESTORE)
+          { const cplx v = make_double2(N1[n][g] + P2[n][g], N3[n][g] - N1[n][g] + P2[n][g]);
+            if (n == 3 && g == 3) *(cplx*)(tb + du + offC) = v; else asm volatile("" ::"v"(v.x), "v"(v.y)); }
+#elif defined(BIEM_ABL_NOSTORE)
+          { const cplx v = make_double2(N1[n][g] + P2[n][g], N3[n][g] - N1[n][g] + P2[n][g]);
+            asm volatile("" ::"v"(v.x), "v"(v.y)); }
 #else
-            const cplx v = make_double2(N1[tm][n][g] + P2[tm][n][g], N3[tm][n][g] - N1[tm][n][g] + P2[tm][n][g]);
-            *(cplx*)(tb + du + offC) = v;
+          const cplx v = make_double2(N1[n][g] + P2[n][g], N3[n][g] - N1[n][g] + P2[n][g]);
+          *(cplx*)(tb + du + offC) = v;
 #endif
-            N1[tm][n][g] = 0.0; P2[tm][n][g] = 0.0; N3[tm][n][g] = 0.0;
-          }
+          N1[n][g] = 0.0; P2[n][g] = 0.0; N3[n][g] = 0.0;
         }
       }
     } else {
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
+      for (int n = 0; n < 4; ++n) {
+        const int col = col0 + n * 16 + l15;
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          const int col = col0 + wn * 32 + n * 16 + l15;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int row = row0 + wm * 32 + tm * 16 + 4 * g + l4;
-            const cplx v = make_double2(N1[tm][n][g] + P2[tm][n][g], N3[tm][n][g] - N1[tm][n][g] + P2[tm][n][g]);
-            if (col < n_cols && row < n_pad) Cs[(size_t)row * lda + col] = v;
-            N1[tm][n][g] = 0.0; P2[tm][n][g] = 0.0; N3[tm][n][g] = 0.0;
-          }
+        for (int g = 0; g < 4; ++g) {
+          const int row = row0 + wave * 16 + 4 * g + l4;
+          const cplx v = make_double2(N1[n][g] + P2[n][g], N3[n][g] - N1[n][g] + P2[n][g]);
+          if (col < n_cols && row < n_pad) Cs[(size_t)row * lda + col] = v;
+          N1[n][g] = 0.0; P2[n][g] = 0.0; N3[n][g] = 0.0;
         }
       }
     }
