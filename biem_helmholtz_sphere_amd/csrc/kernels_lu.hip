@@ -537,7 +537,11 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
           cplx* S2 = ring + st2 * STG;
           const unsigned mA = (unsigned)(size_t)(lds_cplx_t)(S2 + wave * AST), mB = (unsigned)(size_t)(lds_cplx_t)(S2 + BOF + wave * 64);
           const long long dC = ((long long)(4 * (p_ch & 3)) * lda + (p_ch >> 2) * 16) * (long long)sizeof(cplx);
+#ifdef BIEM_ABL_CHOT      // timing ablation: the C slice comes from an L2-resident address (the panel workspace)
+          const char* pCc = (const char*)Pw + (dC & 0xfffff);
+#else
           const char* pCc = pC + dC;
+#endif
           asm volatile(
 #ifndef BIEM_ABL_NOLDS
               "ds_read_b128 %[b0], %[aB]\n\tds_read_b128 %[b1], %[aB] offset:256\n\tds_read_b128 %[b2], %[aB] offset:512\n\tds_read_b128 %[b3], %[aB] offset:768\n\t"
