@@ -239,7 +239,8 @@ int biem_solve(const biem_plan* plan, int nb, int B, int nrhs, const double* d_k
                                  (size_t)L.n_pad * c, st));
     rc = launch_rhs_project(plan, c, B, nrhs, d_g + (size_t)s0 * nrhs * B * Q * 2, A + (size_t)L.n_pad * 2, L.sys_stride, L.lda, 1, st);
     if (rc) return rc;
-    rc = launch_lu_factor_solve(c, L.n_pad, nrhs, A, L.lda, L.sys_stride, ipiv, d_info + s0, Pw, lu_workspace_bytes(c, L.n_pad, nrhs), st);
+    rc = launch_lu_factor_solve(c, L.n_pad, nrhs, A, L.lda, L.sys_stride, ipiv, d_info + s0, Pw, lu_workspace_bytes(c, L.n_pad, nrhs), st,
+                                /*keep_multipliers=*/false);   // the fused path only needs the solution
     if (rc) return rc;
     rc = launch_density(plan, c, B, nrhs, A + (size_t)L.n_pad * 2, L.sys_stride, L.lda, 1, tb, d_density + (size_t)s0 * nrhs * B * H * 2, st);
     if (rc) return rc;

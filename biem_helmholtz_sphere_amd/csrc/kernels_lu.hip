@@ -840,7 +840,7 @@ __global__ void k_zero_int(int* p, int n) {
 }
 
 int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_ipiv,
-                           int* d_info, void* d_work, size_t work_bytes, hipStream_t st) {
+                           int* d_info, void* d_work, size_t work_bytes, hipStream_t st, bool keep_multipliers) {
   if (nb <= 0 || n_pad <= 0) return BIEM_OK;
   if (n_pad % NB) { set_error("biem_lu: n_pad=%d is not a multiple of %d (use biem_lu_npad)", n_pad, NB); return BIEM_ERR_ARG; }
   if (nrhs < 0 || lda < n_pad + nrhs) { set_error("biem_lu: lda < n_pad + nrhs"); return BIEM_ERR_ARG; }
@@ -866,7 +866,11 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
       if (c0 + PW < NB && below > 0)
         hipLaunchKernelGGL(k_panel_update, dim3((below + 255) / 256, nb), dim3(256), 0, st, Pj, ldp, p_stride, n_pad, j, c0);
     }
-    hipLaunchKernelGGL(k_panel_store, dim3((rows + TR - 1) / TR, nb), dim3(256), 0, st, A, lda, sys_stride, Pj, ldp, p_stride, n_pad, j);
+    // back to the row-major matrix: everything (factors for the caller) or only the 64 rows of the diagonal block - U11 is
+    // all the rest of the solve reads from these columns (the trailing updates take L21 from the panel workspace)
+    const int srows = keep_multipliers ? rows : (rows < NB ? rows : NB);
+    hipLaunchKernelGGL(k_panel_store, dim3((srows + TR - 1) / TR, nb), dim3(256), 0, st, A, lda, sys_stride, Pj, ldp, p_stride,
+                       keep_multipliers ? n_pad : j + srows, j);
     if (pc > 0) hipLaunchKernelGGL(k_swap_p, dim3(nb), dim3(64), 0, st, Pw, ldp, p_stride, n_pad, j, d_ipiv);
   };
   // the panel's row interchanges on the columns right of it
