@@ -615,7 +615,10 @@ def biem(
     use_matrix = (not has_rhs) or B > 1 or force_matrix          # reference :643-645
     density_t = None
     with torch.cuda.device(dev):
-        if not use_matrix:
+        if nb == 0:
+            # an empty batch axis: nothing to solve, results of the right (empty) shape
+            density_t = torch.empty((0, nrhs, B, H), dtype=torch.complex128, device=dev) if has_rhs else None
+        elif not use_matrix:
             # single ball: density = f / (blc (alpha h + beta k h'))    (reference :648-691)
             tab = torch.empty((nb, B, 3, n_end), dtype=torch.complex128, device=dev)
             L.check(lib.biem_ball_tables(plan.handle, nb, B, _ptr(fl.k), _ptr(fl.eta), _ptr(fl.radii), fl.geom_batched,
@@ -756,7 +759,7 @@ def biem_u(res: Any, x: Array, /, far_field: bool = False, per_ball: bool = Fals
     with torch.cuda.device(dev):
         wb = int(lib.biem_uscat_workspace_bytes(plan.handle, nb, B))
         work = torch.empty(max(wb, 16), dtype=torch.uint8, device=dev)
-        if P > 0:
+        if P > 0 and nb > 0:
             L.check(lib.biem_uscat(plan.handle, nb, B, P, _ptr(kf), _ptr(ef), _ptr(cf), _ptr(rf), int(geom_b), _ptr(df), _ptr(pts),
                                    flags, _ptr(out), _ptr(work), wb, _stream_ptr(dev)), "biem_uscat")
     out = out.reshape(xshape + batch + ((B,) if per_ball else ()))

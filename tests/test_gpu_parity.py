@@ -492,3 +492,35 @@ def test_many_small_systems_are_chunked(amd):
         uo, _ = O.plane_wave(ks[i], [1.0, 0.0, 0.0])
         res = O.solve_biem("ba", centers=cen, radii=np.ones(2), k=ks[i], n_end=6, uin=uo)
         assert abs(u[i] - O.uscat(res, np.zeros((1, 3)))[0]) < 1e-11 * abs(u[i]), i
+
+
+def test_batched_geometry_and_points_per_system(amd):
+    """Geometry that differs between systems (centers [K, B, d], radii [K, B]) and evaluation points given per system
+    (expand_x=False: x of shape (d, P, K)); every system against its own oracle solve."""
+    c = amd.create_from_branching_types("ba")
+    rng = np.random.default_rng(5)
+    K = 3
+    cen = np.array([[[0.0, 1.7, 0.1], [0.2, -1.6, 0.0]], [[0.3, 2.0, -0.2], [0.0, -1.8, 0.4]], [[-0.4, 1.5, 0.0], [0.5, -2.2, 0.1]]])
+    rad = np.array([[1.0, 0.7], [0.9, 1.1], [0.6, 0.8]])
+    ks = np.array([1.1, 1.9, 2.6])
+    dirs = np.zeros((3, K)); dirs[1] = 1.0
+    uin, ugr = amd.plane_wave(k=_dev(ks), direction=_dev(dirs))
+    calc = amd.biem(c, centers=_dev(cen), radii=_dev(rad), k=_dev(ks), n_end=8, alpha=0.0, beta=1.0, uin=uin, uin_grad=ugr)
+    xs = 6.0 + rng.normal(size=(K, 4, 3))                               # [K, P, d]
+    u = calc.uscat(_dev(np.transpose(xs, (2, 1, 0))), expand_x=False).cpu().numpy()      # (d, P, K) -> [P, K]
+    assert u.shape == (4, K)
+    for i in range(K):
+        uo, go = O.plane_wave(ks[i], [0.0, 1.0, 0.0])
+        res = O.solve_biem("ba", centers=cen[i], radii=rad[i], k=ks[i], n_end=8, alpha=0.0, beta=1.0, uin=uo, uin_grad=go)
+        ref = O.uscat(res, xs[i])
+        assert np.max(np.abs(u[:, i] - ref) / np.abs(ref)) < 1e-10, i
+
+
+def test_empty_batch(amd):
+    """A batch axis of extent 0 yields empty results of the right shape (no kernel is launched on an empty grid)."""
+    c = amd.create_from_branching_types("a")
+    ks = torch.zeros((0,), dtype=torch.float64, device="cuda")
+    uin, _ = amd.plane_wave(k=ks, direction=torch.zeros((2, 0), dtype=torch.float64, device="cuda"))
+    calc = amd.biem(c, centers=_dev([[0.0, 2.0], [0.0, -2.0]])[None], radii=_dev([1.0, 1.0])[None], k=ks, n_end=5, uin=uin)
+    assert tuple(calc.density.shape) == (0, 2, 9)
+    assert tuple(calc.uscat(_dev(np.zeros((2, 3)))).shape) == (3, 0)
