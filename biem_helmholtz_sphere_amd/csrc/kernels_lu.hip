@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) k_panel_store(cplx* __restrict__ A, long 
 constexpr int PW = 8;
 
 __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, long long ldp, long long p_stride, int n_pad, int j, int c0,
-                                                       int* __restrict__ ipiv, int* __restrict__ info) {
+                                                       int second, int* __restrict__ ipiv, int* __restrict__ info) {
   __shared__ double sval[2][16];   // per-wave pivot candidates, double-buffered over columns
   __shared__ int sidx[2][16];
   __shared__ cplx sU[PW];          // current pivot row restricted to the strip
@@ -168,9 +168,11 @@ __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, lon
   const int nright = NB - (c0 + PW);
   if (nright <= 0) return;
   const int rs = j + c0;               // first row of the strip
+  __shared__ cplx sL10[PW][PW];       // second strip of a pair: its rows x the first strip's columns
   if (tid < PW * PW) {
     int q = tid / PW, q2 = tid % PW;   // L[q][q2], q2 < q
     sL[q][q2] = (q2 < q) ? Ps[(size_t)(c0 + q2) * ldp + rs + q] : make_double2(0.0, 0.0);
+    if (second) sL10[q][q2] = Ps[(size_t)(c0 - PW + q2) * ldp + rs + q];
   }
   __syncthreads();
   if (tid < nright) {
@@ -178,6 +180,17 @@ __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, lon
     cplx x[PW];
 #pragma unroll
     for (int q = 0; q < PW; ++q) x[q] = colr[q];
+    if (second) {
+      // the right columns have not received the first strip's update yet (it is applied together with this strip's as one
+      // rank-16 update): bring this strip's rows up to date here, x -= L10 U0, U0 = the first strip's rows of this column
+      cplx u0[PW];
+#pragma unroll
+      for (int q2 = 0; q2 < PW; ++q2) u0[q2] = colr[q2 - PW];
+#pragma unroll
+      for (int q = 0; q < PW; ++q)
+#pragma unroll
+        for (int q2 = 0; q2 < PW; ++q2) x[q] = cfnma(sL10[q][q2], u0[q2], x[q]);
+    }
 #pragma unroll
     for (int q = 1; q < PW; ++q)
 #pragma unroll
@@ -188,32 +201,35 @@ __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, lon
 }
 
 // rows below the strip, right columns:  P[cc][i] -= sum_q L[i][q] U[q][cc];  one thread per row, all CUs
-__global__ void __launch_bounds__(256) k_panel_update(cplx* __restrict__ Pw, long long ldp, long long p_stride, int n_pad, int j, int c0) {
-  __shared__ cplx sUr[PW][NB];
+template <int PWU>
+__global__ void __launch_bounds__(256) k_panel_update(cplx* __restrict__ Pw, long long ldp, long long p_stride, int n_pad, int j, int c0,
+                                                       int ncols) {
+  // rank-PWU update of `ncols` (a multiple of 8) columns right of the PWU factored columns c0 .. c0+PWU-1, rows below them
+  __shared__ cplx sUr[PWU][NB];
   const int s = blockIdx.y, tid = threadIdx.x;
   cplx* Ps = Pw + (size_t)s * p_stride;
-  const int rs = j + c0, nright = NB - (c0 + PW);
-  for (int e = tid; e < nright * PW; e += 256) {
-    int t = e / PW, q = e % PW;
-    sUr[q][t] = Ps[(size_t)(c0 + PW + t) * ldp + rs + q];
+  const int rs = j + c0;
+  for (int e = tid; e < ncols * PWU; e += 256) {
+    int t = e / PWU, q = e % PWU;
+    sUr[q][t] = Ps[(size_t)(c0 + PWU + t) * ldp + rs + q];
   }
   __syncthreads();
-  const int i = rs + PW + blockIdx.x * 256 + tid;
+  const int i = rs + PWU + blockIdx.x * 256 + tid;
   if (i >= n_pad) return;
-  cplx l[PW];
+  cplx l[PWU];
 #pragma unroll
-  for (int q = 0; q < PW; ++q) l[q] = Ps[(size_t)(c0 + q) * ldp + i];
-  // nright is a multiple of PW: 8 independent loads, 64 complex FMAs, 8 stores per group
-  for (int t0 = 0; t0 < nright; t0 += PW) {
-    cplx v[PW];
+  for (int q = 0; q < PWU; ++q) l[q] = Ps[(size_t)(c0 + q) * ldp + i];
+  // 8 independent loads, 8 PWU complex FMAs, 8 stores per group
+  for (int t0 = 0; t0 < ncols; t0 += 8) {
+    cplx v[8];
 #pragma unroll
-    for (int t = 0; t < PW; ++t) v[t] = Ps[(size_t)(c0 + PW + t0 + t) * ldp + i];
+    for (int t = 0; t < 8; ++t) v[t] = Ps[(size_t)(c0 + PWU + t0 + t) * ldp + i];
 #pragma unroll
-    for (int t = 0; t < PW; ++t)
+    for (int t = 0; t < 8; ++t)
 #pragma unroll
-      for (int q = 0; q < PW; ++q) v[t] = cfnma(l[q], sUr[q][t0 + t], v[t]);
+      for (int q = 0; q < PWU; ++q) v[t] = cfnma(l[q], sUr[q][t0 + t], v[t]);
 #pragma unroll
-    for (int t = 0; t < PW; ++t) Ps[(size_t)(c0 + PW + t0 + t) * ldp + i] = v[t];
+    for (int t = 0; t < 8; ++t) Ps[(size_t)(c0 + PWU + t0 + t) * ldp + i] = v[t];
   }
 }
 
@@ -860,11 +876,18 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     const int rows = n_pad - j;
     ProfScope ps(PK_PANEL, st, 4.0 * (double)nb * rows * NB * NB);
     hipLaunchKernelGGL(k_panel_load, dim3((rows + TR - 1) / TR, nb), dim3(256), 0, st, A, lda, sys_stride, Pj, ldp, p_stride, n_pad, j);
-    for (int c0 = 0; c0 < NB; c0 += PW) {
-      hipLaunchKernelGGL(k_panel_strip, dim3(nb), dim3(1024), 0, st, Pj, ldp, p_stride, n_pad, j, c0, d_ipiv, d_info);
-      const int below = n_pad - (j + c0 + PW);
-      if (c0 + PW < NB && below > 0)
-        hipLaunchKernelGGL(k_panel_update, dim3((below + 255) / 256, nb), dim3(256), 0, st, Pj, ldp, p_stride, n_pad, j, c0);
+    // strips in pairs: after the first strip only the second strip's 8 columns are updated (rank 8); the columns right of
+    // the pair get both strips' updates as ONE rank-16 pass (336 instead of 504 column passes per panel through HBM)
+    for (int c0 = 0; c0 < NB; c0 += 2 * PW) {
+      hipLaunchKernelGGL(k_panel_strip, dim3(nb), dim3(1024), 0, st, Pj, ldp, p_stride, n_pad, j, c0, 0, d_ipiv, d_info);
+      int below = n_pad - (j + c0 + PW);
+      if (below > 0)
+        hipLaunchKernelGGL(k_panel_update<PW>, dim3((below + 255) / 256, nb), dim3(256), 0, st, Pj, ldp, p_stride, n_pad, j, c0, PW);
+      hipLaunchKernelGGL(k_panel_strip, dim3(nb), dim3(1024), 0, st, Pj, ldp, p_stride, n_pad, j, c0 + PW, 1, d_ipiv, d_info);
+      below = n_pad - (j + c0 + 2 * PW);
+      const int ncols = NB - (c0 + 2 * PW);
+      if (ncols > 0 && below > 0)
+        hipLaunchKernelGGL(k_panel_update<2 * PW>, dim3((below + 255) / 256, nb), dim3(256), 0, st, Pj, ldp, p_stride, n_pad, j, c0, ncols);
     }
     // back to the row-major matrix: everything (factors for the caller) or only the 64 rows of the diagonal block - U11 is
     // all the rest of the solve reads from these columns (the trailing updates take L21 from the panel workspace)
