@@ -155,7 +155,7 @@ def main():
     # accuracy of this run's densities vs the CPU oracle at probe points (max rel-err, metric's second half)
     cpu = None
     relerr = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:     # the CPU baseline and the accuracy check run at N = 1 only
         res, cpu_dt, threads = cpu_baseline(args.n_end, w["centers_np"], float(w["ks"][0]))
         ang = 2 * np.pi * np.arange(63) / 63
         probes = np.concatenate([np.zeros((1, 3)), np.stack([10.5 * np.cos(ang), 10.5 * np.sin(ang), np.zeros(63)], -1)])
