@@ -531,13 +531,13 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
       __builtin_amdgcn_sched_barrier(0);
       BIEM_TR(2)
       const int st2 = st >= 1 ? st - 1 : 2;            // (st + 2) % 3
-      // interior chunks of the K = 128 kernel put their DMA group between the fragment reads and the lgkmcnt wait (below):
+      // interior chunks put their DMA group between the fragment reads and the lgkmcnt wait (below):
       // the VMEM issue (~100 cycles per instruction with 8 waves' groups in flight) then runs under the LDS latency
 #ifdef BIEM_ABL_NODMA      // timing ablation: no DMA at all (compute-only period)
       const bool fused = false;
       if (p_valid) advance();
 #else
-      const bool fused = UPC == 1 && p_valid && p_interior;
+      const bool fused = p_valid && p_interior;
       if (p_valid && !fused) issue(st2);
 #endif
       __builtin_amdgcn_sched_barrier(0);
@@ -582,6 +582,36 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
                 [b7] "=&v"(fb[1][3]), [c0] "=&v"(cv[0])
               : [aA] "v"(aA), [aB] "v"(aB), [aC] "v"(aC), [mA] "s"(mA), [mB] "s"(mB), [oA0] "v"(offA0), [oA1] "v"(offA1), [oB0] "v"(offB0),
                 [oB1] "v"(offB1), [oC] "v"(offC), [pA] "s"(pA), [pB] "s"(pB), [pC] "s"(pCc)
+              : "memory", "m0", "scc");
+          __builtin_amdgcn_sched_barrier(0);
+          advance();
+        } else if (UPC == 2 && fused) {
+          // the K = 64 form: two C units per chunk (slots mB + 8192 and mB + 12288)
+          typedef __attribute__((address_space(3))) cplx* lds_cplx_t;
+          cplx* S2 = ring + st2 * STG;
+          const unsigned mA = (unsigned)(size_t)(lds_cplx_t)(S2 + wave * AST), mB = (unsigned)(size_t)(lds_cplx_t)(S2 + BOF + wave * 64);
+          const int u0 = p_ch * 2, u1 = u0 + 1;
+          const char* pC0 = pC + ((long long)(4 * (u0 & 3)) * lda + (u0 >> 2) * 16) * (long long)sizeof(cplx);
+          const char* pC1 = pC + ((long long)(4 * (u1 & 3)) * lda + (u1 >> 2) * 16) * (long long)sizeof(cplx);
+          asm volatile(
+              "ds_read_b128 %[b0], %[aB]\n\tds_read_b128 %[b1], %[aB] offset:256\n\tds_read_b128 %[b2], %[aB] offset:512\n\tds_read_b128 %[b3], %[aB] offset:768\n\t"
+              "ds_read_b128 %[b4], %[aB] offset:4096\n\tds_read_b128 %[b5], %[aB] offset:4352\n\tds_read_b128 %[b6], %[aB] offset:4608\n\tds_read_b128 %[b7], %[aB] offset:4864\n\t"
+              "ds_read_b128 %[a0], %[aA]\n\tds_read_b128 %[a1], %[aA] offset:64\n\tds_read_b128 %[a2], %[aA] offset:128\n\tds_read_b128 %[a3], %[aA] offset:192\n\t"
+              "ds_read_b128 %[a4], %[aA] offset:4352\n\tds_read_b128 %[a5], %[aA] offset:4416\n\tds_read_b128 %[a6], %[aA] offset:4480\n\tds_read_b128 %[a7], %[aA] offset:4544\n\t"
+              "ds_read_b128 %[c0], %[aC]\n\tds_read_b128 %[c1], %[aC] offset:4096\n\t"
+              "s_mov_b32 m0, %[mA]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oA0], %[pA]\n\t"
+              "s_add_u32 m0, %[mA], 4352\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oA1], %[pA]\n\t"
+              "s_mov_b32 m0, %[mB]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oB0], %[pB]\n\t"
+              "s_add_u32 m0, %[mB], 4096\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oB1], %[pB]\n\t"
+              "s_add_u32 m0, %[mB], 8192\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oC], %[pC0]\n\t"
+              "s_add_u32 m0, %[mB], 12288\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oC], %[pC1]\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              : [a0] "=&v"(fa[0][0]), [a1] "=&v"(fa[0][1]), [a2] "=&v"(fa[0][2]), [a3] "=&v"(fa[0][3]), [a4] "=&v"(fa[1][0]),
+                [a5] "=&v"(fa[1][1]), [a6] "=&v"(fa[1][2]), [a7] "=&v"(fa[1][3]), [b0] "=&v"(fb[0][0]), [b1] "=&v"(fb[0][1]),
+                [b2] "=&v"(fb[0][2]), [b3] "=&v"(fb[0][3]), [b4] "=&v"(fb[1][0]), [b5] "=&v"(fb[1][1]), [b6] "=&v"(fb[1][2]),
+                [b7] "=&v"(fb[1][3]), [c0] "=&v"(cv[0]), [c1] "=&v"(cv[UPC - 1])
+              : [aA] "v"(aA), [aB] "v"(aB), [aC] "v"(aC), [mA] "s"(mA), [mB] "s"(mB), [oA0] "v"(offA0), [oA1] "v"(offA1), [oB0] "v"(offB0),
+                [oB1] "v"(offB1), [oC] "v"(offC), [pA] "s"(pA), [pB] "s"(pB), [pC0] "s"(pC0), [pC1] "s"(pC1)
               : "memory", "m0", "scc");
           __builtin_amdgcn_sched_barrier(0);
           advance();
