@@ -84,14 +84,29 @@ __global__ void __launch_bounds__(256) k_panel_store(cplx* __restrict__ A, long 
 // ---------------------------------------------------------------------------------------------
 constexpr int PW = 8;
 
+constexpr int STRIP_CACHE_ROWS = 1024;   // rows of the strip kept in LDS (one per thread): 1024 x 8 x 16 B = 128 KiB
+
 __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, long long ldp, long long p_stride, int n_pad, int j, int c0,
                                                        int second, int* __restrict__ ipiv, int* __restrict__ info) {
+  // Thread t owns the fixed rows rs + t + 1024 k of the strip (rs = j + c0).  Its first row (k = 0) lives in LDS for the whole
+  // strip - the strip is read and written once per column pass otherwise, and with every CU running one system's strip the
+  // kernel is bound by that traffic (6.5 TB/s at 256 systems); the upper rows are the ones every pass touches longest.
+  extern __shared__ cplx tile[];   // [PW][STRIP_CACHE_ROWS]: tile[q * 1024 + (row - rs)]
   __shared__ double sval[2][16];   // per-wave pivot candidates, double-buffered over columns
   __shared__ int sidx[2][16];
   __shared__ cplx sU[PW];          // current pivot row restricted to the strip
   __shared__ cplx sL[PW][PW];      // unit-lower strip triangle
   const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   cplx* Ps = Pw + (size_t)s * p_stride;
+  const int rs = j + c0;
+  cplx* Pc = Ps + (size_t)c0 * ldp;
+  const unsigned ldp32 = (unsigned)ldp;
+  const int my0 = rs + tid;                      // the cached row of this thread
+  const bool have0 = my0 < n_pad;
+  auto sget = [&](int q, int row) -> cplx { return row - rs < STRIP_CACHE_ROWS ? tile[q * STRIP_CACHE_ROWS + (row - rs)] : Pc[(unsigned)q * ldp32 + (unsigned)row]; };
+  auto sput = [&](int q, int row, cplx v) {
+    if (row - rs < STRIP_CACHE_ROWS) tile[q * STRIP_CACHE_ROWS + (row - rs)] = v; else Pc[(unsigned)q * ldp32 + (unsigned)row] = v;
+  };
 
   auto publish = [&](double best, int bi, int buf) {
     for (int o = 32; o > 0; o >>= 1) {
@@ -108,12 +123,18 @@ __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, lon
     return ix == 0x7fffffff ? r0 : ix;          // all-NaN column: keep the diagonal
   };
 
-  {  // search the strip's first column
-    const cplx* col = Ps + (size_t)c0 * ldp;
+  {  // stage the cached rows and search the strip's first column
     double best = -1.0; int bi = 0x7fffffff;
-    for (int i = j + c0 + tid; i < n_pad; i += 1024) {
-      cplx v = col[i];
-      double a = fabs(v.x) + fabs(v.y);
+    if (have0) {
+#pragma unroll
+      for (int q = 0; q < PW; ++q) tile[q * STRIP_CACHE_ROWS + tid] = Pc[(unsigned)q * ldp32 + (unsigned)my0];
+      const cplx v = tile[tid];
+      const double a = fabs(v.x) + fabs(v.y);
+      if (a > best) { best = a; bi = my0; }
+    }
+    for (int i = my0 + STRIP_CACHE_ROWS; i < n_pad; i += 1024) {
+      const cplx v = Pc[(unsigned)i];
+      const double a = fabs(v.x) + fabs(v.y);
       if (a > best) { best = a; bi = i; }
     }
     publish(best, bi, 0);
@@ -130,14 +151,15 @@ __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, lon
     const int p = decide(buf, r0);
     if (tid == 0) ipiv[(size_t)s * n_pad + r0] = p;
     if (tid < NB) {
-      cplx a = Ps[(size_t)tid * ldp + r0];
+      const bool mine = tid >= c0 && tid < c0 + PW;     // a strip column: rows may live in LDS
+      cplx a = mine ? sget(tid - c0, r0) : Ps[(size_t)tid * ldp + r0];
       if (p != r0) {
-        cplx b = Ps[(size_t)tid * ldp + p];
-        Ps[(size_t)tid * ldp + p] = a;
-        Ps[(size_t)tid * ldp + r0] = b;
+        cplx b = mine ? sget(tid - c0, p) : Ps[(size_t)tid * ldp + p];
+        if (mine) { sput(tid - c0, p, a); sput(tid - c0, r0, b); }
+        else { Ps[(size_t)tid * ldp + p] = a; Ps[(size_t)tid * ldp + r0] = b; }
         a = b;
       }
-      if (tid >= c0 && tid < c0 + PW) sU[tid - c0] = a;   // row r0 after the interchange, strip columns
+      if (mine) sU[tid - c0] = a;   // row r0 after the interchange, strip columns
     }
     __syncthreads();
     const cplx piv = sU[cq];
@@ -148,10 +170,10 @@ __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, lon
 #pragma unroll
     for (int q = 0; q < PW; ++q) u[q] = sU[q];
     double best = -1.0; int bi = 0x7fffffff;
-    for (int i = r0 + 1 + tid; i < n_pad; i += 1024) {
+    if (have0 && my0 > r0) {                              // the cached row: LDS
       cplx v[PW];
 #pragma unroll
-      for (int q = cq; q < PW; ++q) v[q] = Ps[(size_t)(c0 + q) * ldp + i];
+      for (int q = cq; q < PW; ++q) v[q] = tile[q * STRIP_CACHE_ROWS + tid];
       if (!singular) {
         const cplx l = cmul(v[cq], rinv);
         v[cq] = l;
@@ -159,15 +181,34 @@ __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, lon
         for (int q = cq + 1; q < PW; ++q) v[q] = cfnma(l, u[q], v[q]);
       }
 #pragma unroll
-      for (int q = cq; q < PW; ++q) Ps[(size_t)(c0 + q) * ldp + i] = v[q];
+      for (int q = cq; q < PW; ++q) tile[q * STRIP_CACHE_ROWS + tid] = v[q];
+      if (cq + 1 < PW) { double a = fabs(v[cq + 1 < PW ? cq + 1 : cq].x) + fabs(v[cq + 1 < PW ? cq + 1 : cq].y); if (a > best) { best = a; bi = my0; } }
+    }
+    for (int i = my0 + STRIP_CACHE_ROWS; i < n_pad; i += 1024) {     // the other rows: global memory (always below r0)
+      cplx v[PW];
+#pragma unroll
+      for (int q = cq; q < PW; ++q) v[q] = Pc[(unsigned)q * ldp32 + (unsigned)i];
+      if (!singular) {
+        const cplx l = cmul(v[cq], rinv);
+        v[cq] = l;
+#pragma unroll
+        for (int q = cq + 1; q < PW; ++q) v[q] = cfnma(l, u[q], v[q]);
+      }
+#pragma unroll
+      for (int q = cq; q < PW; ++q) Pc[(unsigned)q * ldp32 + (unsigned)i] = v[q];
       if (cq + 1 < PW) { double a = fabs(v[cq + 1 < PW ? cq + 1 : cq].x) + fabs(v[cq + 1 < PW ? cq + 1 : cq].y); if (a > best) { best = a; bi = i; } }
     }
     if (cq + 1 < PW) { publish(best, bi, buf ^ 1); buf ^= 1; }
     __syncthreads();
   }
+  // cached rows back to the panel
+  if (have0) {
+#pragma unroll
+    for (int q = 0; q < PW; ++q) Pc[(unsigned)q * ldp32 + (unsigned)my0] = tile[q * STRIP_CACHE_ROWS + tid];
+  }
+  __syncthreads();
   const int nright = NB - (c0 + PW);
   if (nright <= 0) return;
-  const int rs = j + c0;               // first row of the strip
   __shared__ cplx sL10[PW][PW];       // second strip of a pair: its rows x the first strip's columns
   if (tid < PW * PW) {
     int q = tid / PW, q2 = tid % PW;   // L[q][q2], q2 < q
@@ -897,6 +938,8 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
   const long long ldp = ldp_of(n_pad), p_stride = 2LL * NB * ldp;
   const int n_cols = n_pad + nrhs;
   hipLaunchKernelGGL(k_zero_int, dim3((nb + 63) / 64), dim3(64), 0, st, d_info, nb);
+  const size_t strip_lds = (size_t)PW * STRIP_CACHE_ROWS * sizeof(cplx);
+  BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_panel_strip, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds));
   // (per call, not once per process: the attribute belongs to the current device)
   BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_inv_l11, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * NB * NB * sizeof(cplx))));
 
@@ -909,11 +952,11 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     // strips in pairs: after the first strip only the second strip's 8 columns are updated (rank 8); the columns right of
     // the pair get both strips' updates as ONE rank-16 pass (336 instead of 504 column passes per panel through HBM)
     for (int c0 = 0; c0 < NB; c0 += 2 * PW) {
-      hipLaunchKernelGGL(k_panel_strip, dim3(nb), dim3(1024), 0, st, Pj, ldp, p_stride, n_pad, j, c0, 0, d_ipiv, d_info);
+      hipLaunchKernelGGL(k_panel_strip, dim3(nb), dim3(1024), strip_lds, st, Pj, ldp, p_stride, n_pad, j, c0, 0, d_ipiv, d_info);
       int below = n_pad - (j + c0 + PW);
       if (below > 0)
         hipLaunchKernelGGL(k_panel_update<PW>, dim3((below + 255) / 256, nb), dim3(256), 0, st, Pj, ldp, p_stride, n_pad, j, c0, PW);
-      hipLaunchKernelGGL(k_panel_strip, dim3(nb), dim3(1024), 0, st, Pj, ldp, p_stride, n_pad, j, c0 + PW, 1, d_ipiv, d_info);
+      hipLaunchKernelGGL(k_panel_strip, dim3(nb), dim3(1024), strip_lds, st, Pj, ldp, p_stride, n_pad, j, c0 + PW, 1, d_ipiv, d_info);
       below = n_pad - (j + c0 + 2 * PW);
       const int ncols = NB - (c0 + 2 * PW);
       if (ncols > 0 && below > 0)
