@@ -301,7 +301,7 @@ int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const doub
     BIEM_LAUNCHCHK();
   }
   size_t shm = (size_t)(p->H2 + 2 * H) * sizeof(cplx) + (size_t)p->chunk_terms_max * 10 + (size_t)(p->chunk_ents_max + 1) * 4 + 16;
-  if (shm > 160 * 1024 || p->chunk_terms_max == 0 && p->coef.size() > 0) {
+  if (shm > 160 * 1024 || (p->chunk_terms_max == 0 && p->coef.size() > 0)) {
     set_error("biem_fill: tables do not fit LDS (H2=%d, chunk terms=%d)", p->H2, p->chunk_terms_max);
     return BIEM_ERR_UNSUPPORTED;
   }

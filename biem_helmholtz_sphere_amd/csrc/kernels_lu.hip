@@ -583,7 +583,6 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
 #endif
       __builtin_amdgcn_sched_barrier(0);
       BIEM_TR(3)
-      const cplx* S = ring + st * STG;
       // fragments of both k4-steps and the C units of this chunk: 20 + UPC ds_read_b128 and their lgkmcnt wait in ONE asm
       // statement - hipcc may copy an asm output right after the statement, i.e. before a separate wait (that was the
       // cause of percent-level errors in an earlier build); byte offsets: k4*4352 + g*64 (A), k4*4096 + n*256 (B)

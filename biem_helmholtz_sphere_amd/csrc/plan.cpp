@@ -188,7 +188,7 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
   } else if (tree == TREE_CAA) {
     // int Y' conj(Y) conj(Y'') = delta(m1'' = m1' - m1) delta(m2'' = m2' - m2) / (2 pi) * int cbar' cbar cbar'' sin cos dt;
     // the polar integrand is a polynomial of degree <= 2 n_end - 2 in x = cos 2t: Gauss-Legendre with 2 n_end nodes is exact
-    const int n2 = p->n2, nq = 2 * n;
+    const int nq = 2 * n;
     std::vector<double> xg, wg; gauss_legendre(nq, xg, wg);
     std::map<int, std::vector<double>> cb;      // key (n, a, b) -> values at the nodes
     auto key = [](int q, int a, int b) { return (q * 256 + a) * 256 + b; };
