@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X FP64 matrix, vendor spec (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
-CLASSES = ["tables", "fill", "rhs", "panel", "swap", "trsm", "gemm", "back", "gemm_k64"]
+CLASSES = ["tables", "fill", "rhs", "panel", "swap", "trsm", "gemm", "back", "gemm_small"]
 
 
 def workload(n_sys_total: int, rank: int, world: int, per_gpu: int, dev):
@@ -193,7 +193,7 @@ def main():
                    "systems_per_gpu": per_gpu, "parallelism": f"batch-shard x{world}"},
         "max_rel_err_uscat": relerr,
         "roofline": {
-            "bound": "mfma", "kernel": "k_gemm3m_pipe<128> (zgemm3m trailing update, v_mfma_f64_4x4x4_4b_f64)",
+            "bound": "mfma", "kernel": "k_gemm3m_pipe<256> (zgemm3m trailing update of a four-panel group, v_mfma_f64_4x4x4_4b_f64)",
             "achieved": gemm_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": (gemm_tflops / FP64_MFMA_PEAK_TFLOPS) if gemm_tflops else None,
             "traffic": traffic,

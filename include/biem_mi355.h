@@ -151,8 +151,9 @@ int biem_solve(const biem_plan* plan, int nb, int B, int nrhs, const double* d_k
 /* ---- per-kernel-class timing with HIP events on the launch stream (thread-local; used by bench.py for the
  *      live `roofline` figures).  Between begin and end every launch of the calling thread is bracketed by two
  *      events; end synchronises on them and returns, per class, elapsed ms, algorithmic work and launch count.
- *      Classes: 0 tables, 1 fill (work = bytes written), 2 rhs, 3 panel, 4 swap, 5 trsm, 6 gemm = the K=128 trailing
- *      updates (work = real flops, 8 per complex multiply-add), 7 back substitution, 8 the K=64 updates inside a block. */
+ *      Classes: 0 tables, 1 fill (work = bytes written), 2 rhs, 3 panel, 4 swap, 5 trsm, 6 gemm = the K=256 trailing
+ *      updates of the four-panel groups (work = real flops, 8 per complex multiply-add), 7 back substitution, 8 the K=64 and
+ *      K=128 updates inside a group. */
 #define BIEM_PROFILE_CLASSES 9
 int biem_profile_begin(void);
 int biem_profile_end(double* ms /*[9]*/, double* work /*[9]*/, long long* launches /*[9]*/);
