@@ -10,7 +10,7 @@
 //                the f64 MFMA A-fragment wants, so it is staged to LDS without a transpose)
 //   swap         row interchanges on the columns outside the panel (coalesced: rows are contiguous)
 //   trsm         U12 = L11^{-1} M[j:j+NB, j+NB:]   (includes the right-hand-side columns: forward elimination rides along)
-//   gemm         M[j+NB:, j+NB:] -= L21 * U12      zgemm on v_mfma_f64_16x16x4_f64 (4 real MFMAs per complex tile-step)
+//   gemm         M[j+NB:, j+NB:] -= L21 * U12      3M zgemm on v_mfma_f64_4x4x4_4b_f64 (k_gemm3m_pipe; K = 64 / 128 / 256)
 // then a blocked back substitution with U.  All kernels are batched over systems (blockIdx.z / .y).
 #include "common.hpp"
 #include <cstdlib>

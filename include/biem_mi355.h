@@ -118,7 +118,8 @@ int biem_fill(const biem_plan* plan, int nb, int B, const double* d_k /*c128*/, 
               int n_pad, void* d_work, size_t work_bytes, void* stream);
 
 /* ---- dense complex LU (batch_tensorsolve.btensorsolve -> linalg.solve, _biem.py:797) ----
- * Right-looking blocked LU with partial (row) pivoting; trailing updates are zgemm on v_mfma_f64_16x16x4_f64.
+ * Right-looking blocked LU with partial (row) pivoting in groups of four 64-column panels; trailing updates are 3M zgemm
+ * (K = 64 / 128 inside a group, one K = 256 update per group) on v_mfma_f64_4x4x4_4b_f64.
  * The system is the augmented row-major [A | F]: Npad rows, Npad + nrhs columns, leading dimension lda >= Npad + nrhs.
  * biem_lu_factor_solve overwrites F with the solution (forward elimination rides in the trailing update, then a
  * blocked back substitution); A is overwritten by U and the un-permuted multipliers. */
