@@ -139,7 +139,9 @@ def test_fill_reference_scaling_vs_oracle(amd, tree, n_end, B):
 
 
 # ---------------------------------------------------------------------------- LU
-@pytest.mark.parametrize("N,nb,nrhs", [(64, 3, 1), (72, 2, 2), (200, 2, 1), (576, 1, 3), (1000, 2, 1)])
+# n_pad = 1, 2, 3, 4 panels (one group of the K = 256 schedule and its tails), 5, 6, 7 (a group plus every tail), 9, 16
+@pytest.mark.parametrize("N,nb,nrhs", [(64, 3, 1), (72, 2, 2), (150, 2, 3), (200, 2, 1), (300, 2, 2), (380, 1, 9), (440, 2, 1),
+                                       (576, 1, 3), (1000, 2, 1)])
 def test_lu_factor_solve_vs_numpy(lib, N, nb, nrhs):
     l, L = lib
     rng = np.random.default_rng(N)
