@@ -880,6 +880,8 @@ static void launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, l
     hipLaunchKernelGGL(k_gemm3m_pipe<64>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
   else if (kd == 256)
     hipLaunchKernelGGL(k_gemm3m_pipe<256>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
+  else if (kd == 192)
+    hipLaunchKernelGGL(k_gemm3m_pipe<192>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
   else
     hipLaunchKernelGGL(k_gemm3m_pipe<128>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
 }
@@ -1043,7 +1045,8 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     //      of; b: factor, interchanges (also on a's stored multipliers); only now - with the rows in their final order - a's
     //      update of the 64 rows of b's U block, then b's U row block.
     //   E's K = 128 update is applied only where block O needs it: O's 128 columns before O is factored (T1, all rows), and the
-    //      64 U rows of c and of d right of O after the respective panel's interchanges (T2c, T2d).
+    //      64 U rows of c and of d right of O after the respective panel's interchanges (T2c; for d fused with c's own update
+    //      of those rows into one K = 192 pass).
     //   block O = (c, d): the same as E, its interchanges also applied to E's multipliers in the workspace.
     //   ONE K = 256 update of everything below and right of the group with [L_a L_b L_c L_d] x [U_a; U_b; U_c; U_d]: the
     //   trailing matrix is read and written once per 256 columns instead of once per 128 (77 vs 65 TFLOP/s for the update
@@ -1069,8 +1072,8 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
       if (J + 3 * NB >= n_pad) break;
       launch_gemm_stream(st, nb, A, lda, sys_stride, Po, ldp, p_stride, J + 3 * NB, n_pad, J + 3 * NB, J + 4 * NB, J + 2 * NB, NB, PK_OTHER);
       panel(J + 3 * NB, 3 * NB); swap_right(J + 3 * NB);
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 3 * NB, J + 4 * NB, J + 4 * NB, n_cols, J, 2 * NB, PK_OTHER);   // T2d
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Po, ldp, p_stride, J + 3 * NB, J + 4 * NB, J + 4 * NB, n_cols, J + 2 * NB, NB, PK_OTHER);
+      // T2d and c's update of d's U rows in one K = 192 pass: [L_a L_b L_c] x [U_a; U_b; U_c]
+      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 3 * NB, J + 4 * NB, J + 4 * NB, n_cols, J, 3 * NB, PK_OTHER);
       trsm(J + 3 * NB, 3 * NB);
       launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 4 * NB, n_pad, J + 4 * NB, n_cols, J, 4 * NB);
     }
