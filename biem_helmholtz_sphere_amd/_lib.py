@@ -69,9 +69,15 @@ def load() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             # not a fallback: the same HIP library, compiled now if the toolchain is present
             try:
+                import fcntl
+
                 from . import _build
 
-                _build.build(force=True)
+                # several ranks may get here at once (one process per GPU): one builds, the others wait and re-check
+                with open(LIB_PATH + ".lock", "w") as lk:
+                    fcntl.flock(lk, fcntl.LOCK_EX)
+                    if not os.path.exists(LIB_PATH):
+                        _build.build(force=True)
             except Exception as e:  # noqa: BLE001
                 raise BiemLibraryError(
                     f"{LIB_PATH} is missing and could not be built ({e}). Build it with "
