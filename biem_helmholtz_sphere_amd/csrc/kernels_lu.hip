@@ -596,6 +596,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
       // statement - hipcc may copy an asm output right after the statement, i.e. before a separate wait (that was the
       // cause of percent-level errors in an earlier build); byte offsets: k4*4352 + g*64 (A), k4*4096 + n*256 (B)
       cplx fb[2][4], fa[2][4], cv[UPC];   // [k4][column group of 16], [k4][row quad]
+      unsigned m0_keep;                    // M0 is compiler-reserved: the fused statements save and restore it
       {
         if (UPC == 1 && fused && (NCC == NCH || p_ch < NCC)) {
           typedef __attribute__((address_space(3))) cplx* lds_cplx_t;
@@ -616,6 +617,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
               "ds_read_b128 %[c0], %[aC]\n\t"
 #endif
 #ifndef BIEM_ABL_ONLYCDMA
+              "s_mov_b32 %[keep], m0\n\t"
               "s_mov_b32 m0, %[mA]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oA0], %[pA]\n\t"
               "s_add_u32 m0, %[mA], 4352\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oA1], %[pA]\n\t"
               "s_mov_b32 m0, %[mB]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oB0], %[pB]\n\t"
@@ -624,14 +626,15 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
 #ifndef BIEM_ABL_NOCDMA
               "s_add_u32 m0, %[mB], 8192\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oC], %[pC]\n\t"
 #endif
+              "s_mov_b32 m0, %[keep]\n\t"
               "s_waitcnt lgkmcnt(0)"
-              : [a0] "=&v"(fa[0][0]), [a1] "=&v"(fa[0][1]), [a2] "=&v"(fa[0][2]), [a3] "=&v"(fa[0][3]), [a4] "=&v"(fa[1][0]),
+              : [keep] "=&s"(m0_keep), [a0] "=&v"(fa[0][0]), [a1] "=&v"(fa[0][1]), [a2] "=&v"(fa[0][2]), [a3] "=&v"(fa[0][3]), [a4] "=&v"(fa[1][0]),
                 [a5] "=&v"(fa[1][1]), [a6] "=&v"(fa[1][2]), [a7] "=&v"(fa[1][3]), [b0] "=&v"(fb[0][0]), [b1] "=&v"(fb[0][1]),
                 [b2] "=&v"(fb[0][2]), [b3] "=&v"(fb[0][3]), [b4] "=&v"(fb[1][0]), [b5] "=&v"(fb[1][1]), [b6] "=&v"(fb[1][2]),
                 [b7] "=&v"(fb[1][3]), [c0] "=&v"(cv[0])
               : [aA] "v"(aA), [aB] "v"(aB), [aC] "v"(aC), [mA] "s"(mA), [mB] "s"(mB), [oA0] "v"(offA0), [oA1] "v"(offA1), [oB0] "v"(offB0),
                 [oB1] "v"(offB1), [oC] "v"(offC), [pA] "s"(pA), [pB] "s"(pB), [pC] "s"(pCc)
-              : "memory", "m0", "scc");
+              : "memory", "scc");
           __builtin_amdgcn_sched_barrier(0);
           n_new = NDMA;
           advance();
@@ -648,19 +651,21 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
               "ds_read_b128 %[c0], %[aC]\n\t"
 #endif
 #ifndef BIEM_ABL_ONLYCDMA
+              "s_mov_b32 %[keep], m0\n\t"
               "s_mov_b32 m0, %[mA]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oA0], %[pA]\n\t"
               "s_add_u32 m0, %[mA], 4352\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oA1], %[pA]\n\t"
               "s_mov_b32 m0, %[mB]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oB0], %[pB]\n\t"
               "s_add_u32 m0, %[mB], 4096\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oB1], %[pB]\n\t"
 #endif
+              "s_mov_b32 m0, %[keep]\n\t"
               "s_waitcnt lgkmcnt(0)"
-              : [a0] "=&v"(fa[0][0]), [a1] "=&v"(fa[0][1]), [a2] "=&v"(fa[0][2]), [a3] "=&v"(fa[0][3]), [a4] "=&v"(fa[1][0]),
+              : [keep] "=&s"(m0_keep), [a0] "=&v"(fa[0][0]), [a1] "=&v"(fa[0][1]), [a2] "=&v"(fa[0][2]), [a3] "=&v"(fa[0][3]), [a4] "=&v"(fa[1][0]),
                 [a5] "=&v"(fa[1][1]), [a6] "=&v"(fa[1][2]), [a7] "=&v"(fa[1][3]), [b0] "=&v"(fb[0][0]), [b1] "=&v"(fb[0][1]),
                 [b2] "=&v"(fb[0][2]), [b3] "=&v"(fb[0][3]), [b4] "=&v"(fb[1][0]), [b5] "=&v"(fb[1][1]), [b6] "=&v"(fb[1][2]),
                 [b7] "=&v"(fb[1][3]), [c0] "=&v"(cv[0])
               : [aA] "v"(aA), [aB] "v"(aB), [aC] "v"(aC), [mA] "s"(mA), [mB] "s"(mB), [oA0] "v"(offA0), [oA1] "v"(offA1), [oB0] "v"(offB0),
                 [oB1] "v"(offB1), [pA] "s"(pA), [pB] "s"(pB)
-              : "memory", "m0", "scc");
+              : "memory", "scc");
           __builtin_amdgcn_sched_barrier(0);
           n_new = NDMA - UPC;
           advance();
@@ -678,20 +683,22 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
               "ds_read_b128 %[a0], %[aA]\n\tds_read_b128 %[a1], %[aA] offset:64\n\tds_read_b128 %[a2], %[aA] offset:128\n\tds_read_b128 %[a3], %[aA] offset:192\n\t"
               "ds_read_b128 %[a4], %[aA] offset:4352\n\tds_read_b128 %[a5], %[aA] offset:4416\n\tds_read_b128 %[a6], %[aA] offset:4480\n\tds_read_b128 %[a7], %[aA] offset:4544\n\t"
               "ds_read_b128 %[c0], %[aC]\n\tds_read_b128 %[c1], %[aC] offset:4096\n\t"
+              "s_mov_b32 %[keep], m0\n\t"
               "s_mov_b32 m0, %[mA]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oA0], %[pA]\n\t"
               "s_add_u32 m0, %[mA], 4352\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oA1], %[pA]\n\t"
               "s_mov_b32 m0, %[mB]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oB0], %[pB]\n\t"
               "s_add_u32 m0, %[mB], 4096\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oB1], %[pB]\n\t"
               "s_add_u32 m0, %[mB], 8192\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oC], %[pC0]\n\t"
               "s_add_u32 m0, %[mB], 12288\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[oC], %[pC1]\n\t"
+              "s_mov_b32 m0, %[keep]\n\t"
               "s_waitcnt lgkmcnt(0)"
-              : [a0] "=&v"(fa[0][0]), [a1] "=&v"(fa[0][1]), [a2] "=&v"(fa[0][2]), [a3] "=&v"(fa[0][3]), [a4] "=&v"(fa[1][0]),
+              : [keep] "=&s"(m0_keep), [a0] "=&v"(fa[0][0]), [a1] "=&v"(fa[0][1]), [a2] "=&v"(fa[0][2]), [a3] "=&v"(fa[0][3]), [a4] "=&v"(fa[1][0]),
                 [a5] "=&v"(fa[1][1]), [a6] "=&v"(fa[1][2]), [a7] "=&v"(fa[1][3]), [b0] "=&v"(fb[0][0]), [b1] "=&v"(fb[0][1]),
                 [b2] "=&v"(fb[0][2]), [b3] "=&v"(fb[0][3]), [b4] "=&v"(fb[1][0]), [b5] "=&v"(fb[1][1]), [b6] "=&v"(fb[1][2]),
                 [b7] "=&v"(fb[1][3]), [c0] "=&v"(cv[0]), [c1] "=&v"(cv[UPC - 1])
               : [aA] "v"(aA), [aB] "v"(aB), [aC] "v"(aC), [mA] "s"(mA), [mB] "s"(mB), [oA0] "v"(offA0), [oA1] "v"(offA1), [oB0] "v"(offB0),
                 [oB1] "v"(offB1), [oC] "v"(offC), [pA] "s"(pA), [pB] "s"(pB), [pC0] "s"(pC0), [pC1] "s"(pC1)
-              : "memory", "m0", "scc");
+              : "memory", "scc");
           __builtin_amdgcn_sched_barrier(0);
           n_new = NDMA;
           advance();
