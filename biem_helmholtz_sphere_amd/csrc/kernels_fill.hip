@@ -242,9 +242,16 @@ __global__ void __launch_bounds__(FILL_THREADS) k_fill(int H, int H2, int n_end,
         const int h = (e0 + e) / H, hp = (e0 + e) - h * H;
         const int nh = deg[h];
         const cplx raw = make_double2(sr, si);
+#ifdef BIEM_ABL_FILL_NOSTORE       // timing ablation: results computed, not stored
+        const cplx v1 = cmul(cmul(raw, tb[nh]), sC[hp]);
+        const cplx m = cmul(cmul(raw, tbp[nh]), sC2[hp]);
+        asm volatile("" ::"v"(v1.x), "v"(v1.y), "v"(m.x), "v"(m.y));
+        (void)Ab; (void)Am;
+#else
         Ab[(size_t)h * lda + hp] = cmul(cmul(raw, tb[nh]), sC[hp]);
         const cplx m = cmul(cmul(raw, tbp[nh]), sC2[hp]);
         Am[(size_t)h * lda + hp] = ((nh + deg[hp]) & 1) ? make_double2(-m.x, -m.y) : m;
+#endif
       };
       for (int e = tid; e < nent; e += 2 * FILL_THREADS) {
         const int eb = e + FILL_THREADS;
