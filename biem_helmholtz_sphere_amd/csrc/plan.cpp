@@ -260,7 +260,7 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
   p->tidx16.resize(p->tidx.size());
   for (size_t i = 0; i < p->tidx.size(); ++i) p->tidx16[i] = (uint16_t)p->tidx[i];
   {
-    const int max_ents = 4096;
+    const int max_ents = 1024;                                     // = FILL_THREADS of the fill kernel: one entry per thread
     const long long budget = 150 * 1024 - (long long)(p->H2 + 2 * H) * 16 - (long long)(max_ents + 1) * 4 - 64;
     long long cap_terms = budget > 0 ? budget / 10 : 0;            // 8-byte coefficient + 2-byte table index per term
     if (cap_terms > 16384) cap_terms = 16384;
