@@ -957,22 +957,32 @@ __global__ void __launch_bounds__(64) k_back_diag(cplx* __restrict__ A, long lon
 }
 
 // rows above: y[i] -= sum_c U[i][jr+c] x[jr+c]; one wave per row
+constexpr int BACK_ROWS = 16;   // rows per workgroup of the back-substitution update (4 per wave)
 __global__ void __launch_bounds__(256) k_back_update(cplx* __restrict__ A, long long lda, long long sys_stride, int n_pad, int nrhs, int jr) {
-  const int s = blockIdx.y, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= jr) return;
+  // y[i] -= U[i, jr:jr+64] . x[jr:jr+64] for the rows above the solved block.  The 64 solution values are strided by lda in
+  // memory (one cache line each): they are gathered ONCE per workgroup into LDS instead of once per row
+  __shared__ cplx sx[BS];
+  const int s = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   cplx* As = A + (size_t)s * sys_stride;
-  cplx u = As[(size_t)i * lda + jr + lane];
   for (int q = 0; q < nrhs; ++q) {
-    cplx x = As[(size_t)(jr + lane) * lda + n_pad + q];
-    cplx v = cmul(u, x);
-    double vr = v.x, vi = v.y;
-    for (int o = 32; o > 0; o >>= 1) { vr += __shfl_down(vr, o, 64); vi += __shfl_down(vi, o, 64); }
-    if (lane == 0) {
-      cplx* y = As + (size_t)i * lda + n_pad + q;
-      cplx t = *y;
-      t.x -= vr; t.y -= vi;
-      *y = t;
+    if (q > 0) __syncthreads();
+    if (threadIdx.x < BS) sx[threadIdx.x] = As[(size_t)(jr + threadIdx.x) * lda + n_pad + q];
+    __syncthreads();
+    const cplx x = sx[lane];
+#pragma unroll
+    for (int k = 0; k < BACK_ROWS / 4; ++k) {
+      const int i = blockIdx.x * BACK_ROWS + wave * (BACK_ROWS / 4) + k;
+      if (i >= jr) break;
+      const cplx u = As[(size_t)i * lda + jr + lane];
+      const cplx v = cmul(u, x);
+      double vr = v.x, vi = v.y;
+      for (int o = 32; o > 0; o >>= 1) { vr += __shfl_down(vr, o, 64); vi += __shfl_down(vi, o, 64); }
+      if (lane == 0) {
+        cplx* y = As + (size_t)i * lda + n_pad + q;
+        cplx t = *y;
+        t.x -= vr; t.y -= vi;
+        *y = t;
+      }
     }
   }
 }
@@ -1091,7 +1101,7 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     for (int jr = n_pad - BS; jr >= 0; jr -= BS) {
       hipLaunchKernelGGL(k_back_diag, dim3(nb, nrhs), dim3(64), 0, st, A, lda, sys_stride, n_pad, jr);
       if (jr > 0)
-        hipLaunchKernelGGL(k_back_update, dim3((jr + 3) / 4, nb), dim3(256), 0, st, A, lda, sys_stride, n_pad, nrhs, jr);
+        hipLaunchKernelGGL(k_back_update, dim3((jr + BACK_ROWS - 1) / BACK_ROWS, nb), dim3(256), 0, st, A, lda, sys_stride, n_pad, nrhs, jr);
     }
     BIEM_LAUNCHCHK();
   }
