@@ -1,5 +1,6 @@
 // abi.cpp -- extern "C" entry points of libbiem_mi355.so (declared in include/biem_mi355.h).
 #include "common.hpp"
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -146,7 +147,10 @@ size_t biem_lu_workspace_bytes(int nb, int n_pad, int nrhs) { return lu_workspac
 int biem_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_ipiv, int* d_info,
                          void* d_work, size_t work_bytes, void* stream) {
   NEED(d_A, "d_A"); NEED(d_ipiv, "d_ipiv"); NEED(d_info, "d_info"); NEED(d_work, "d_work");
-  return launch_lu_factor_solve(nb, n_pad, nrhs, d_A, lda, sys_stride, d_ipiv, d_info, d_work, work_bytes, (hipStream_t)stream);
+  // BIEM_LU_DISCARD_FACTORS=1 (tests): solve exactly as the fused path does, without storing the multipliers back
+  const char* e = getenv("BIEM_LU_DISCARD_FACTORS");
+  return launch_lu_factor_solve(nb, n_pad, nrhs, d_A, lda, sys_stride, d_ipiv, d_info, d_work, work_bytes, (hipStream_t)stream,
+                                !(e && e[0] == '1'));
 }
 
 int biem_density(const biem_plan* plan, int nb, int B, int nrhs, const double* d_x, long long sys_stride, long long elem_stride,

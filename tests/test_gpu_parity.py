@@ -526,3 +526,11 @@ def test_empty_batch(amd):
     calc = amd.biem(c, centers=_dev([[0.0, 2.0], [0.0, -2.0]])[None], radii=_dev([1.0, 1.0])[None], k=ks, n_end=5, uin=uin)
     assert tuple(calc.density.shape) == (0, 2, 9)
     assert tuple(calc.uscat(_dev(np.zeros((2, 3)))).shape) == (3, 0)
+
+
+@pytest.mark.parametrize("N,nb,nrhs", [(440, 2, 2), (1000, 1, 1)])
+def test_lu_solve_without_stored_factors(lib, N, nb, nrhs, monkeypatch):
+    """The fused path (biem_solve) keeps L21 only in the panel workspace; the same mode of the stand-alone LU on Gaussian
+    matrices (heavy pivoting across the panels of a four-panel group): the solution must not depend on it."""
+    monkeypatch.setenv("BIEM_LU_DISCARD_FACTORS", "1")
+    test_lu_factor_solve_vs_numpy(lib, N, nb, nrhs)
