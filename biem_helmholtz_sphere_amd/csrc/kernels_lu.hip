@@ -326,6 +326,9 @@ struct TileGrid {
   int ty_n, tx_n, per_sys, full_bands, ntiles;
   int row_begin, row_end, col_begin, col_end;   // C region updated by this launch
   int brow;                                     // first row of the B operand (U12 rows brow .. brow + K)
+  // tiles of tile column `pcol_tx` deliver their result transposed into the panel workspace (the next panel to factor:
+  // column-major P[c][row]) instead of the matrix, which saves that panel's transposing load; pout == nullptr: off
+  cplx* pout; long long pout_ld, pout_stride; int pcol_tx;
 };
 
 __device__ inline void tile_decode(const TileGrid& tg, int t, int& s, int& ty, int& tx) {
@@ -820,7 +823,19 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
     cplx* Cs = A + (size_t)cs * sys_stride;
     const int row0 = tg.row_begin + cty * BM3, col0 = tg.col_begin + ctx * BN3;
     const bool full = row0 + BM3 <= n_pad && col0 + BN3 <= n_cols;
-    if (full) {
+    if (full && tg.pout != nullptr && ctx == tg.pcol_tx) {
+      // P[(16 n + l15)][row0 + 16 w + 4 g + l4]: 64-byte runs (4 rows) per lane quad; the 64-column panel tiles are always full
+      cplx* Po = tg.pout + (size_t)cs * tg.pout_stride + (size_t)l15 * tg.pout_ld + (row0 + wave * 16 + l4);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const cplx v = make_double2(N1[n][g] + P2[n][g], N3[n][g] - N1[n][g] + P2[n][g]);
+          Po[(size_t)(16 * n) * tg.pout_ld + 4 * g] = v;
+          N1[n][g] = 0.0; P2[n][g] = 0.0; N3[n][g] = 0.0;
+        }
+      }
+    } else if (full) {
       char* tb = (char*)(Cs + (size_t)row0 * lda + col0);
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
@@ -872,10 +887,12 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
 // C[row_begin:row_end, col_begin:col_end] -= P[0:kd]^T (rows of the region) * M[brow:brow+kd, cols of the region]
 static void launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, long long sys_stride, const cplx* Pw, long long ldp,
                                long long p_stride, int row_begin, int row_end, int col_begin, int col_end, int brow, int kd,
-                               int prof_class = PK_GEMM, double prof_work = -1.0) {
+                               int prof_class = PK_GEMM, double prof_work = -1.0, cplx* pout = nullptr, long long pout_ld = 0,
+                               long long pout_stride = 0, int pcol_tx = 0) {
   const int rrows = row_end - row_begin, rcols = col_end - col_begin;
   if (rrows <= 0 || rcols <= 0) return;
   TileGrid tg;
+  tg.pout = pout; tg.pout_ld = pout_ld; tg.pout_stride = pout_stride; tg.pcol_tx = pcol_tx;
   tg.ty_n = (rrows + BM3 - 1) / BM3; tg.tx_n = (rcols + BN3 - 1) / BN3;
   tg.per_sys = tg.ty_n * tg.tx_n; tg.full_bands = tg.ty_n / 8; tg.ntiles = tg.per_sys * nb;
   tg.row_begin = row_begin; tg.row_end = row_end; tg.col_begin = col_begin; tg.col_end = col_end; tg.brow = brow;
@@ -1010,11 +1027,12 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
   BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_inv_l11, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * NB * NB * sizeof(cplx))));
 
   // factor the 64-column panel at column j, multipliers into P columns [pc, pc + NB)
-  auto panel = [&](int j, int pc) {
+  auto panel = [&](int j, int pc, bool in_workspace = false) {
     cplx* Pj = Pw + (size_t)pc * ldp;
     const int rows = n_pad - j;
     ProfScope ps(PK_PANEL, st, 4.0 * (double)nb * rows * NB * NB);
-    hipLaunchKernelGGL(k_panel_load, dim3((rows + TR - 1) / TR, nb), dim3(256), 0, st, A, lda, sys_stride, Pj, ldp, p_stride, n_pad, j);
+    if (!in_workspace)     // (panels b, c, d of a group arrive in the workspace straight from the update that produced them)
+      hipLaunchKernelGGL(k_panel_load, dim3((rows + TR - 1) / TR, nb), dim3(256), 0, st, A, lda, sys_stride, Pj, ldp, p_stride, n_pad, j);
     // strips in pairs: after the first strip only the second strip's 8 columns are updated (rank 8); the columns right of
     // the pair get both strips' updates as ONE rank-16 pass (336 instead of 504 column passes per panel through HBM)
     for (int c0 = 0; c0 < NB; c0 += 2 * PW) {
@@ -1071,24 +1089,27 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     for (int J = 0; J < n_pad; J += 4 * NB) {
       panel(J, 0); swap_right(J); trsm(J, 0);
       if (J + NB >= n_pad) break;                        // odd tail: nothing below the panel, forward elimination done
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + NB, n_pad, J + NB, J + 2 * NB, J, NB, PK_OTHER);
-      panel(J + NB, NB); swap_right(J + NB);
+      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + NB, n_pad, J + NB, J + 2 * NB, J, NB, PK_OTHER, -1.0,
+                         Pw + (size_t)NB * ldp, ldp, p_stride, 0);
+      panel(J + NB, NB, true); swap_right(J + NB);
       launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + NB, J + 2 * NB, J + 2 * NB, n_cols, J, NB, PK_OTHER);
       trsm(J + NB, NB);
       if (J + 2 * NB >= n_pad) break;
       const int oc_end = J + 4 * NB < n_pad ? J + 4 * NB : n_pad;     // end of block O's columns / rows
       // T1: E's update of block O's columns, ALL rows below E (the rows O's pivot search ranges over must be in one state)
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 2 * NB, n_pad, J + 2 * NB, oc_end, J, 2 * NB, PK_OTHER);
+      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 2 * NB, n_pad, J + 2 * NB, oc_end, J, 2 * NB, PK_OTHER, -1.0,
+                         Pw + (size_t)(2 * NB) * ldp, ldp, p_stride, 0);          // its first 64 columns = panel c -> workspace
       const cplx* Po = Pw + (size_t)(2 * NB) * ldp;                    // block O's multipliers
-      panel(J + 2 * NB, 2 * NB); swap_right(J + 2 * NB);
+      panel(J + 2 * NB, 2 * NB, true); swap_right(J + 2 * NB);
       // T2c: E's update of c's 64 U rows right of O - only now, after c's interchanges: rows that an interchange can exchange
       // must carry the same updates, and the rows below still wait for the K = 256 update
       launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 2 * NB, J + 3 * NB < n_pad ? J + 3 * NB : n_pad, oc_end, n_cols,
                          J, 2 * NB, PK_OTHER);
       trsm(J + 2 * NB, 2 * NB);
       if (J + 3 * NB >= n_pad) break;
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Po, ldp, p_stride, J + 3 * NB, n_pad, J + 3 * NB, J + 4 * NB, J + 2 * NB, NB, PK_OTHER);
-      panel(J + 3 * NB, 3 * NB); swap_right(J + 3 * NB);
+      launch_gemm_stream(st, nb, A, lda, sys_stride, Po, ldp, p_stride, J + 3 * NB, n_pad, J + 3 * NB, J + 4 * NB, J + 2 * NB, NB, PK_OTHER, -1.0,
+                         Pw + (size_t)(3 * NB) * ldp, ldp, p_stride, 0);
+      panel(J + 3 * NB, 3 * NB, true); swap_right(J + 3 * NB);
       // T2d and c's update of d's U rows in one K = 192 pass: [L_a L_b L_c] x [U_a; U_b; U_c]
       launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 3 * NB, J + 4 * NB, J + 4 * NB, n_cols, J, 3 * NB, PK_OTHER);
       trsm(J + 3 * NB, 3 * NB);
