@@ -1095,19 +1095,19 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
       launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + NB, J + 2 * NB, J + 2 * NB, n_cols, J, NB, PK_OTHER);
       trsm(J + NB, NB);
       if (J + 2 * NB >= n_pad) break;
-      const int oc_end = J + 4 * NB < n_pad ? J + 4 * NB : n_pad;     // end of block O's columns / rows
-      // T1: E's update of block O's columns, ALL rows below E (the rows O's pivot search ranges over must be in one state)
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 2 * NB, n_pad, J + 2 * NB, oc_end, J, 2 * NB, PK_OTHER, -1.0,
-                         Pw + (size_t)(2 * NB) * ldp, ldp, p_stride, 0);          // its first 64 columns = panel c -> workspace
-      const cplx* Po = Pw + (size_t)(2 * NB) * ldp;                    // block O's multipliers
+      // T1: E's update of panel c's columns, ALL rows below E (the rows c's pivot search ranges over must be in one state);
+      // the result goes straight into the workspace.  d's columns wait: they take E's and c's updates in one K = 192 pass.
+      const int c_end = J + 3 * NB < n_pad ? J + 3 * NB : n_pad;
+      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 2 * NB, n_pad, J + 2 * NB, c_end, J, 2 * NB, PK_OTHER, -1.0,
+                         Pw + (size_t)(2 * NB) * ldp, ldp, p_stride, 0);
       panel(J + 2 * NB, 2 * NB, true); swap_right(J + 2 * NB);
-      // T2c: E's update of c's 64 U rows right of O - only now, after c's interchanges: rows that an interchange can exchange
+      // T2c: E's update of c's 64 U rows right of c - only now, after c's interchanges: rows that an interchange can exchange
       // must carry the same updates, and the rows below still wait for the K = 256 update
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 2 * NB, J + 3 * NB < n_pad ? J + 3 * NB : n_pad, oc_end, n_cols,
-                         J, 2 * NB, PK_OTHER);
+      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 2 * NB, c_end, c_end, n_cols, J, 2 * NB, PK_OTHER);
       trsm(J + 2 * NB, 2 * NB);
       if (J + 3 * NB >= n_pad) break;
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Po, ldp, p_stride, J + 3 * NB, n_pad, J + 3 * NB, J + 4 * NB, J + 2 * NB, NB, PK_OTHER, -1.0,
+      // d's columns: E's and c's updates in one K = 192 pass, delivered into the workspace
+      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 3 * NB, n_pad, J + 3 * NB, J + 4 * NB, J, 3 * NB, PK_OTHER, -1.0,
                          Pw + (size_t)(3 * NB) * ldp, ldp, p_stride, 0);
       panel(J + 3 * NB, 3 * NB, true); swap_right(J + 3 * NB);
       // T2d and c's update of d's U rows in one K = 192 pass: [L_a L_b L_c] x [U_a; U_b; U_c]
