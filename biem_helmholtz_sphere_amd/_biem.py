@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import warnings
 from dataclasses import dataclass
 from typing import Any, Callable, Literal, Optional, Protocol, Tuple, TypedDict
@@ -52,6 +53,9 @@ def _harm_n_ndim_le(n_end: int, c_ndim: int) -> int:
     # dim of polynomials of degree <= n_end-1 restricted to harmonics: C(n+d-2, d-1) + C(n+d-3, d-1), n = n_end-1
     n = n_end - 1
     return math.comb(n + c_ndim - 1, c_ndim - 1) + math.comb(n + c_ndim - 2, c_ndim - 1)
+
+
+_last_solve_stats: dict = {}   # how the last biem() call solved its systems (tests / bench)
 
 
 def max_memory(*, c_ndim: int, n_end: int, n_balls: int) -> int:
@@ -642,9 +646,33 @@ def biem(
             work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
             density_t = torch.empty((nb, nrhs, B, H), dtype=torch.complex128, device=dev)
             info = torch.zeros(nb, dtype=torch.int32, device=dev)
-            L.check(lib.biem_solve(plan.handle, nb, B, nrhs, _ptr(fl.k), _ptr(fl.eta), _ptr(fl.centers), _ptr(fl.radii), fl.geom_batched,
-                                   _ptr(fl.alpha), _ptr(fl.beta), fl.ab_batched, _ptr(g), _ptr(density_t), _ptr(info), chunk,
-                                   _ptr(work), wbytes, sp), "biem_solve")
+            # The equilibrated system is complex symmetric in a real-harmonic basis (include/biem_mi355.h, biem_solve_ldlt):
+            # L D L^T without interchanges, half the flops of the LU.  Systems whose diagonal pivots were rejected
+            # (info < 0: close to a resonance of a sphere, or strongly coupled spheres) are solved again with the pivoted LU,
+            # which is what the reference's linalg.solve does for every system (_biem.py:797).  BIEM_SOLVER=lu: LU only.
+            solver = os.environ.get("BIEM_SOLVER", "ldlt")
+            if solver not in ("ldlt", "lu"):
+                raise ValueError(f"BIEM_SOLVER must be 'ldlt' or 'lu', got {solver!r}")
+            entry = lib.biem_solve_ldlt if solver == "ldlt" else lib.biem_solve
+            L.check(entry(plan.handle, nb, B, nrhs, _ptr(fl.k), _ptr(fl.eta), _ptr(fl.centers), _ptr(fl.radii), fl.geom_batched,
+                          _ptr(fl.alpha), _ptr(fl.beta), fl.ab_batched, _ptr(g), _ptr(density_t), _ptr(info), chunk,
+                          _ptr(work), wbytes, sp), "biem_solve")
+            if solver == "ldlt":
+                redo = torch.nonzero(info < 0).flatten()
+                if redo.numel() > 0:
+                    nr = int(redo.numel())
+                    pick = lambda t, batched: t[redo].contiguous() if batched else t
+                    k_r, eta_r, g_r = fl.k[redo].contiguous(), fl.eta[redo].contiguous(), g[redo].contiguous()
+                    cen_r, rad_r = pick(fl.centers, fl.geom_batched), pick(fl.radii, fl.geom_batched)
+                    al_r, be_r = pick(fl.alpha, fl.ab_batched), pick(fl.beta, fl.ab_batched)
+                    dens_r = torch.empty((nr, nrhs, B, H), dtype=torch.complex128, device=dev)
+                    info_r = torch.zeros(nr, dtype=torch.int32, device=dev)
+                    L.check(lib.biem_solve(plan.handle, nr, B, nrhs, _ptr(k_r), _ptr(eta_r), _ptr(cen_r), _ptr(rad_r), fl.geom_batched,
+                                           _ptr(al_r), _ptr(be_r), fl.ab_batched, _ptr(g_r), _ptr(dens_r), _ptr(info_r), min(chunk, nr),
+                                           _ptr(work), wbytes, sp), "biem_solve")
+                    density_t[redo] = dens_r
+            _last_solve_stats["ldlt_systems"] = nb if solver == "ldlt" else 0
+            _last_solve_stats["lu_systems"] = (int(redo.numel()) if solver == "ldlt" else nb)
             del work
 
     def make_matrix():

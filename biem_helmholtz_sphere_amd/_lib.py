@@ -47,6 +47,8 @@ SIGNATURES = {
     "biem_uscat": (_i, [_vp, _i, _i, _i, _dp, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _vp, _sz, _vp]),
     "biem_solve_workspace_bytes": (_sz, [_vp, _i, _i, _i, _i]),
     "biem_solve": (_i, [_vp, _i, _i, _i, _dp, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _dp, _ip, _i, _vp, _sz, _vp]),
+    "biem_solve_ldlt": (_i, [_vp, _i, _i, _i, _dp, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _dp, _ip, _i, _vp, _sz, _vp]),
+    "biem_ldlt_factor_solve": (_i, [_i, _i, _i, _dp, _ll, _ll, _ip, _ip, _vp, _sz, _vp]),
     "biem_profile_begin": (_i, []),
     "biem_profile_end": (_i, [_vp, _vp, _vp]),
     "biem_bench_mfma_f64": (_i, [_i, C.POINTER(C.c_double), _vp]),

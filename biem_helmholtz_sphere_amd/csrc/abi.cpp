@@ -153,6 +153,14 @@ int biem_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda
                                 !(e && e[0] == '1'));
 }
 
+int biem_ldlt_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_ipiv, int* d_info,
+                           void* d_work, size_t work_bytes, void* stream) {
+  NEED(d_A, "d_A"); NEED(d_ipiv, "d_ipiv"); NEED(d_info, "d_info"); NEED(d_work, "d_work");
+  const char* e = getenv("BIEM_LU_DISCARD_FACTORS");
+  return launch_lu_factor_solve(nb, n_pad, nrhs, d_A, lda, sys_stride, d_ipiv, d_info, d_work, work_bytes, (hipStream_t)stream,
+                                !(e && e[0] == '1'), /*symmetric=*/true);
+}
+
 int biem_density(const biem_plan* plan, int nb, int B, int nrhs, const double* d_x, long long sys_stride, long long elem_stride,
                  long long rhs_stride, const double* d_tab, double* d_density, void* stream) {
   NEED_DEV(plan); NEED(d_x, "d_x"); NEED(d_tab, "d_tab"); NEED(d_density, "d_density");
@@ -211,9 +219,10 @@ size_t biem_solve_workspace_bytes(const biem_plan* plan, int nb, int B, int nrhs
   return make_layout(plan, nb, B, nrhs, chunk).total;
 }
 
-int biem_solve(const biem_plan* plan, int nb, int B, int nrhs, const double* d_k, const double* d_eta, const double* d_centers,
+static int solve_impl(const biem_plan* plan, int nb, int B, int nrhs, const double* d_k, const double* d_eta, const double* d_centers,
                const double* d_radii, int geom_batched, const double* d_alpha, const double* d_beta, int ab_batched,
-               const double* d_g, double* d_density, int* d_info, int chunk, void* d_work, size_t work_bytes, void* stream) {
+               const double* d_g, double* d_density, int* d_info, int chunk, void* d_work, size_t work_bytes, void* stream,
+               bool symmetric) {
   NEED_DEV(plan); NEED(d_k, "d_k"); NEED(d_eta, "d_eta"); NEED(d_centers, "d_centers"); NEED(d_radii, "d_radii");
   NEED(d_alpha, "d_alpha"); NEED(d_beta, "d_beta"); NEED(d_g, "d_g"); NEED(d_density, "d_density"); NEED(d_info, "d_info"); NEED(d_work, "d_work");
   if (nb <= 0 || B <= 0) return BIEM_OK;
@@ -243,13 +252,35 @@ int biem_solve(const biem_plan* plan, int nb, int B, int nrhs, const double* d_k
                                  (size_t)L.n_pad * c, st));
     rc = launch_rhs_project(plan, c, B, nrhs, d_g + (size_t)s0 * nrhs * B * Q * 2, A + (size_t)L.n_pad * 2, L.sys_stride, L.lda, 1, st);
     if (rc) return rc;
+    if (symmetric) {
+      rc = launch_symmetrize(plan, c, B, nrhs, L.n_pad, tb, A, L.lda, L.sys_stride, false, st);
+      if (rc) return rc;
+    }
     rc = launch_lu_factor_solve(c, L.n_pad, nrhs, A, L.lda, L.sys_stride, ipiv, d_info + s0, Pw, lu_workspace_bytes(c, L.n_pad, nrhs), st,
-                                /*keep_multipliers=*/false);   // the fused path only needs the solution
+                                /*keep_multipliers=*/false, symmetric);   // the fused path only needs the solution
     if (rc) return rc;
+    if (symmetric) {
+      rc = launch_symmetrize(plan, c, B, nrhs, L.n_pad, tb, A, L.lda, L.sys_stride, true, st);
+      if (rc) return rc;
+    }
     rc = launch_density(plan, c, B, nrhs, A + (size_t)L.n_pad * 2, L.sys_stride, L.lda, 1, tb, d_density + (size_t)s0 * nrhs * B * H * 2, st);
     if (rc) return rc;
   }
   return BIEM_OK;
+}
+
+int biem_solve(const biem_plan* plan, int nb, int B, int nrhs, const double* d_k, const double* d_eta, const double* d_centers,
+               const double* d_radii, int geom_batched, const double* d_alpha, const double* d_beta, int ab_batched,
+               const double* d_g, double* d_density, int* d_info, int chunk, void* d_work, size_t work_bytes, void* stream) {
+  return solve_impl(plan, nb, B, nrhs, d_k, d_eta, d_centers, d_radii, geom_batched, d_alpha, d_beta, ab_batched, d_g, d_density, d_info,
+                    chunk, d_work, work_bytes, stream, false);
+}
+
+int biem_solve_ldlt(const biem_plan* plan, int nb, int B, int nrhs, const double* d_k, const double* d_eta, const double* d_centers,
+                    const double* d_radii, int geom_batched, const double* d_alpha, const double* d_beta, int ab_batched,
+                    const double* d_g, double* d_density, int* d_info, int chunk, void* d_work, size_t work_bytes, void* stream) {
+  return solve_impl(plan, nb, B, nrhs, d_k, d_eta, d_centers, d_radii, geom_batched, d_alpha, d_beta, ab_batched, d_g, d_density, d_info,
+                    chunk, d_work, work_bytes, stream, true);
 }
 
 int biem_profile_begin(void) {

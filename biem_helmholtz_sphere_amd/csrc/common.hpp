@@ -86,7 +86,11 @@ int launch_uscat(const biem_plan* p, int nb, int B, int P, const double* d_k, co
 int lu_npad(int N);
 size_t lu_workspace_bytes(int nb, int n_pad, int nrhs);
 int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_ipiv,
-                           int* d_info, void* d_work, size_t work_bytes, hipStream_t st, bool keep_multipliers = true);
+                           int* d_info, void* d_work, size_t work_bytes, hipStream_t st, bool keep_multipliers = true,
+                           bool symmetric = false);
+// [M | F] -> complex-symmetric [R W^H M W R^-1 | R W^H F] in place (inverse_on_solution: x = W R^-1 x~ on the solution columns)
+int launch_symmetrize(const biem_plan* p, int nb, int B, int nrhs, int n_pad, const double* d_tab, double* d_A, long long lda,
+                      long long sys_stride, bool inverse_on_solution, hipStream_t st);
 int bench_mfma_f64(int iters, double* tflops, hipStream_t st);
 
 }  // namespace biem

@@ -380,6 +380,96 @@ int launch_rhs_project(const biem_plan* p, int nb, int B, int nrhs, const double
 }
 
 // ---------------------------------------------------------------------------------------------
+// complex-symmetric form of the equilibrated system (for the L D L^T path).
+// With W the unitary map to real harmonics (pairs h <= p, conj Y_h = Y_p:  W e_h = (e_h + e_p)/sqrt2,  W e_p = i (e_p - e_h)/sqrt2)
+// and R = diag(1 / sqrt(gj gh)) per (ball, degree),   A~ = R W^H M W R^{-1}   is complex symmetric  (G P symmetric, see
+// tests/test_oracle_golden.py::test_translation_block_matrix_is_complex_symmetric_up_to_conjugate_pairing), f~ = R W^H f,
+// and the solution of the original system is x = W R^{-1} x~.
+// k_symmetrize: one thread per (row unit, column unit) 2 x 2 block of [M | F], in place; right-hand-side columns take the row
+// transform only.  k_unsymmetrize: x from x~ in the right-hand-side columns.
+// ---------------------------------------------------------------------------------------------
+__device__ inline cplx sym_r(const cplx* __restrict__ tball, int n_end, int n) {   // 1 / sqrt(gj gh)
+  return crecip(zsqrt(cmul(tball[n], tball[n_end + n])));
+}
+
+__global__ void __launch_bounds__(256) k_symmetrize(int H, int U, int n_end, int B, int nrhs, int n_pad, const int* __restrict__ units,
+                                                     const int* __restrict__ deg, const cplx* __restrict__ tab, cplx* __restrict__ A,
+                                                     long long lda, long long sys_stride) {
+  const int s = blockIdx.z, ru = blockIdx.y;                    // row unit over all balls
+  const int cu = blockIdx.x * 256 + threadIdx.x;                // column unit over all balls, then the right-hand sides
+  if (cu >= B * U + nrhs) return;
+  const int br = ru / U, ur = ru - br * U;
+  const int rh = units[2 * ur], rp = units[2 * ur + 1];
+  const cplx* ts = tab + (size_t)s * B * 3 * n_end;
+  const cplx rr = sym_r(ts + (size_t)br * 3 * n_end, n_end, deg[rh]);
+  cplx* As = A + (size_t)s * sys_stride;
+  cplx* row_h = As + (size_t)(br * H + rh) * lda;
+  cplx* row_p = As + (size_t)(br * H + rp) * lda;
+  const double q2 = 0.70710678118654752440;
+  int ch, cp; cplx scale;
+  if (cu < B * U) {
+    const int bc = cu / U, uc = cu - bc * U;
+    ch = bc * H + units[2 * uc]; cp = bc * H + units[2 * uc + 1];
+    scale = cmul(rr, zsqrt(cmul(ts[(size_t)bc * 3 * n_end + deg[units[2 * uc]]], ts[(size_t)bc * 3 * n_end + n_end + deg[units[2 * uc]]])));   // r_row / r_col
+  } else { ch = cp = n_pad + (cu - B * U); scale = rr; }
+  cplx x00 = row_h[ch], x01 = row_h[cp], x10 = x00, x11 = x01;
+  if (rp != rh) { x10 = row_p[ch]; x11 = row_p[cp]; }
+  if (rp != rh) {   // rows: (h + p)/sqrt2, i (h - p)/sqrt2
+    cplx a0 = make_double2((x00.x + x10.x) * q2, (x00.y + x10.y) * q2), a1 = make_double2((x01.x + x11.x) * q2, (x01.y + x11.y) * q2);
+    cplx d0 = make_double2((x00.x - x10.x) * q2, (x00.y - x10.y) * q2), d1 = make_double2((x01.x - x11.x) * q2, (x01.y - x11.y) * q2);
+    x00 = a0; x01 = a1; x10 = make_double2(-d0.y, d0.x); x11 = make_double2(-d1.y, d1.x);
+  }
+  if (cp != ch) {   // columns: (h + p)/sqrt2, i (p - h)/sqrt2
+    cplx a0 = make_double2((x00.x + x01.x) * q2, (x00.y + x01.y) * q2), d0 = make_double2((x01.x - x00.x) * q2, (x01.y - x00.y) * q2);
+    cplx a1 = make_double2((x10.x + x11.x) * q2, (x10.y + x11.y) * q2), d1 = make_double2((x11.x - x10.x) * q2, (x11.y - x10.y) * q2);
+    x00 = a0; x01 = make_double2(-d0.y, d0.x); x10 = a1; x11 = make_double2(-d1.y, d1.x);
+  }
+  row_h[ch] = cmul(x00, scale);
+  if (cp != ch) row_h[cp] = cmul(x01, scale);
+  if (rp != rh) {
+    row_p[ch] = cmul(x10, scale);
+    if (cp != ch) row_p[cp] = cmul(x11, scale);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_unsymmetrize(int H, int U, int n_end, int B, int nrhs, int n_pad, const int* __restrict__ units,
+                                                       const int* __restrict__ deg, const cplx* __restrict__ tab, cplx* __restrict__ A,
+                                                       long long lda, long long sys_stride) {
+  const int s = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;                 // (row unit over all balls, rhs)
+  if (t >= B * U * nrhs) return;
+  const int q = t % nrhs, ru = t / nrhs, br = ru / U, ur = ru - br * U;
+  const int rh = units[2 * ur], rp = units[2 * ur + 1];
+  const cplx* ts = tab + (size_t)s * B * 3 * n_end + (size_t)br * 3 * n_end;
+  const cplx g = zsqrt(cmul(ts[deg[rh]], ts[n_end + deg[rh]]));      // 1 / r
+  cplx* As = A + (size_t)s * sys_stride + n_pad + q;
+  cplx* ph = As + (size_t)(br * H + rh) * lda;
+  cplx* pp = As + (size_t)(br * H + rp) * lda;
+  const cplx yh = cmul(*ph, g);
+  if (rp == rh) { *ph = yh; return; }
+  const cplx yp = cmul(*pp, g);
+  const double q2 = 0.70710678118654752440;                            // x_h = (y_h - i y_p)/sqrt2, x_p = (y_h + i y_p)/sqrt2
+  *ph = make_double2((yh.x + yp.y) * q2, (yh.y - yp.x) * q2);
+  *pp = make_double2((yh.x - yp.y) * q2, (yh.y + yp.x) * q2);
+}
+
+int launch_symmetrize(const biem_plan* p, int nb, int B, int nrhs, int n_pad, const double* d_tab, double* d_A, long long lda,
+                      long long sys_stride, bool inverse_on_solution, hipStream_t st) {
+  const int U = (int)(p->units.size() / 2);
+  if (nb <= 0 || B <= 0) return BIEM_OK;
+  if (nb > 65535 || B * U > 65535) { set_error("biem symmetric path: nb and n_balls * units must be <= 65535"); return BIEM_ERR_ARG; }
+  ProfScope ps(PK_SWAP, st, 0.0);   // class 4: row interchanges in the LU, this transform in the symmetric path
+  if (!inverse_on_solution)
+    hipLaunchKernelGGL(k_symmetrize, dim3((B * U + nrhs + 255) / 256, B * U, nb), dim3(256), 0, st, p->H, U, p->n_end, B, nrhs, n_pad,
+                       p->d_units, p->d_deg, (const cplx*)d_tab, (cplx*)d_A, lda, sys_stride);
+  else
+    hipLaunchKernelGGL(k_unsymmetrize, dim3((B * U * nrhs + 255) / 256, nb), dim3(256), 0, st, p->H, U, p->n_end, B, nrhs, n_pad,
+                       p->d_units, p->d_deg, (const cplx*)d_tab, (cplx*)d_A, lda, sys_stride);
+  BIEM_LAUNCHCHK();
+  return BIEM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // density = x / (gh * blc)   (reference scaling of the unknown; single-ball shortcut _biem.py:673-690 with x = f)
 // ---------------------------------------------------------------------------------------------
 __global__ void k_density(int H, int n_end, int B, int nrhs, long long total, const int* __restrict__ deg, const cplx* __restrict__ x,

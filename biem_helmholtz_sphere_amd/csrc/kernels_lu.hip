@@ -84,10 +84,14 @@ __global__ void __launch_bounds__(256) k_panel_store(cplx* __restrict__ A, long 
 // ---------------------------------------------------------------------------------------------
 constexpr int PW = 8;
 
+constexpr double NOPIV_REL = 0.1;        // no-pivot path: smallest accepted |diagonal| / column maximum (element growth <= 11 per step)
 constexpr int STRIP_CACHE_ROWS = 1024;   // rows of the strip kept in LDS (one per thread): 1024 x 8 x 16 B = 128 KiB
 
 __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, long long ldp, long long p_stride, int n_pad, int j, int c0,
-                                                       int second, int* __restrict__ ipiv, int* __restrict__ info) {
+                                                       int second, int* __restrict__ ipiv, int* __restrict__ info, double nopiv_rel) {
+  // nopiv_rel > 0 (symmetric LDL^T path): the pivot is the diagonal entry; the column maximum is still searched and a diagonal
+  // below nopiv_rel times it marks the system (info = -(row + 1)) so that the caller can redo it with the pivoted factorisation.
+  const bool nopiv = nopiv_rel > 0.0;
   // Thread t owns the fixed rows rs + t + 1024 k of the strip (rs = j + c0).  Its first row (k = 0) lives in LDS for the whole
   // strip - the strip is read and written once per column pass otherwise, and with every CU running one system's strip the
   // kernel is bound by that traffic (6.5 TB/s at 256 systems); the upper rows are the ones every pass touches longest.
@@ -116,11 +120,13 @@ __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, lon
     }
     if (lane == 0) { sval[buf][wave] = best; sidx[buf][wave] = bi; }
   };
+  double colmax = 0.0;                          // the searched column's maximum (cabs1), for the no-pivot check
   auto decide = [&](int buf, int r0) -> int {   // every thread reduces the 16 candidates redundantly (no extra barrier)
     double b = sval[buf][0]; int ix = sidx[buf][0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) { double v = sval[buf][w]; int i2 = sidx[buf][w]; if (v > b || (v == b && i2 < ix)) { b = v; ix = i2; } }
-    return ix == 0x7fffffff ? r0 : ix;          // all-NaN column: keep the diagonal
+    colmax = b;
+    return (ix == 0x7fffffff || nopiv) ? r0 : ix;          // all-NaN column: keep the diagonal
   };
 
   {  // stage the cached rows and search the strip's first column
@@ -165,6 +171,7 @@ __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, lon
     const cplx piv = sU[cq];
     const bool singular = piv.x == 0.0 && piv.y == 0.0;
     if (singular && tid == 0 && info[s] == 0) info[s] = r0 + 1;
+    if (nopiv && tid == 0 && !(fabs(piv.x) + fabs(piv.y) >= nopiv_rel * colmax) && info[s] == 0) info[s] = -(r0 + 1);
     const cplx rinv = singular ? make_double2(0.0, 0.0) : crecip(piv);
     cplx u[PW];
 #pragma unroll
@@ -329,11 +336,29 @@ struct TileGrid {
   // tiles of tile column `pcol_tx` deliver their result transposed into the panel workspace (the next panel to factor:
   // column-major P[c][row]) instead of the matrix, which saves that panel's transposing load; pout == nullptr: off
   cplx* pout; long long pout_ld, pout_stride; int pcol_tx;
+  int tri;                                      // 1: only tiles with tx <= ty (square region, symmetric update)
 };
 
 __device__ inline void tile_decode(const TileGrid& tg, int t, int& s, int& ty, int& tx) {
   s = t / tg.per_sys;
   int r = t - s * tg.per_sys;
+  if (tg.tri) {
+    // lower triangle incl. the diagonal tiles, same band order: band b (tile rows 8b .. 8b+hb-1) holds the columns
+    // 0 .. 8b+hb-1; column tx <= 8b has hb tiles, column 8b+q has hb-q.  Full bands hold 64 b + 36 tiles, 32 b^2 + 4 b before.
+    int b = (int)((sqrtf(16.0f + 128.0f * (float)r) - 4.0f) * (1.0f / 64.0f));
+    if (b > tg.full_bands) b = tg.full_bands;
+    while (b > 0 && 32 * b * b + 4 * b > r) --b;
+    while (b < tg.full_bands && 32 * (b + 1) * (b + 1) + 4 * (b + 1) <= r) ++b;
+    const int hb = (b < tg.full_bands) ? 8 : tg.ty_n - 8 * tg.full_bands;
+    int rr = r - (32 * b * b + 4 * b);
+    if (rr < 8 * b * hb) { tx = rr / hb; ty = 8 * b + rr - tx * hb; }
+    else {
+      int rem = rr - 8 * b * hb, q = 0;
+      while (rem >= hb - q) { rem -= hb - q; ++q; }
+      tx = 8 * b + q; ty = 8 * b + q + rem;
+    }
+    return;
+  }
   int fb = tg.full_bands * 8 * tg.tx_n;
   if (r < fb) {
     int band = r / (8 * tg.tx_n), rr = r - band * 8 * tg.tx_n;
@@ -888,18 +913,18 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
 static void launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, long long sys_stride, const cplx* Pw, long long ldp,
                                long long p_stride, int row_begin, int row_end, int col_begin, int col_end, int brow, int kd,
                                int prof_class = PK_GEMM, double prof_work = -1.0, cplx* pout = nullptr, long long pout_ld = 0,
-                               long long pout_stride = 0, int pcol_tx = 0) {
+                               long long pout_stride = 0, int pcol_tx = 0, int tri = 0) {
   const int rrows = row_end - row_begin, rcols = col_end - col_begin;
   if (rrows <= 0 || rcols <= 0) return;
   TileGrid tg;
-  tg.pout = pout; tg.pout_ld = pout_ld; tg.pout_stride = pout_stride; tg.pcol_tx = pcol_tx;
+  tg.pout = pout; tg.pout_ld = pout_ld; tg.pout_stride = pout_stride; tg.pcol_tx = pcol_tx; tg.tri = tri;
   tg.ty_n = (rrows + BM3 - 1) / BM3; tg.tx_n = (rcols + BN3 - 1) / BN3;
-  tg.per_sys = tg.ty_n * tg.tx_n; tg.full_bands = tg.ty_n / 8; tg.ntiles = tg.per_sys * nb;
+  tg.per_sys = tri ? tg.ty_n * (tg.ty_n + 1) / 2 : tg.ty_n * tg.tx_n; tg.full_bands = tg.ty_n / 8; tg.ntiles = tg.per_sys * nb;
   tg.row_begin = row_begin; tg.row_end = row_end; tg.col_begin = col_begin; tg.col_end = col_end; tg.brow = brow;
   const int cap = 512;                         // persistent grid: 2 workgroups per CU
   int want = (tg.ntiles + 7) / 8 * 8;          // one workgroup per tile up to the cap, multiple of 8
   int grid = want < cap ? want : cap;
-  ProfScope ps(prof_class, st, prof_work >= 0.0 ? prof_work : 8.0 * (double)nb * rrows * (double)rcols * kd);
+  ProfScope ps(prof_class, st, prof_work >= 0.0 ? prof_work : 8.0 * (double)nb * (tri ? (double)tg.per_sys * BM3 * BN3 : rrows * (double)rcols) * kd);
   if (kd == 64)
     hipLaunchKernelGGL(k_gemm3m_pipe<64>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
   else if (kd == 256)
@@ -1009,8 +1034,20 @@ __global__ void k_zero_int(int* p, int n) {
   if (i < n) p[i] = 0;
 }
 
+// U rows of a factored panel from its multipliers, symmetric path: U[j+i][c] = d_i L[c][i] for the columns c right of the panel
+// (A = L D L^T, so U = D L^T needs no triangular solve and no pending updates).  P is column-major: both sides are contiguous in c.
+__global__ void __launch_bounds__(256) k_u_from_l(cplx* __restrict__ A, long long lda, long long sys_stride, const cplx* __restrict__ Pj,
+                                                   long long ldp, long long p_stride, int n_pad, int j) {
+  const int s = blockIdx.z, i = blockIdx.y;
+  const int c = j + NB + blockIdx.x * 256 + threadIdx.x;
+  if (c >= n_pad) return;
+  const cplx* Pi = Pj + (size_t)s * p_stride + (size_t)i * ldp;
+  const cplx d = Pi[j + i];
+  A[(size_t)s * sys_stride + (size_t)(j + i) * lda + c] = cmul(d, Pi[c]);
+}
+
 int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_ipiv,
-                           int* d_info, void* d_work, size_t work_bytes, hipStream_t st, bool keep_multipliers) {
+                           int* d_info, void* d_work, size_t work_bytes, hipStream_t st, bool keep_multipliers, bool symmetric) {
   if (nb <= 0 || n_pad <= 0) return BIEM_OK;
   if (n_pad % NB) { set_error("biem_lu: n_pad=%d is not a multiple of %d (use biem_lu_npad)", n_pad, NB); return BIEM_ERR_ARG; }
   if (nrhs < 0 || lda < n_pad + nrhs) { set_error("biem_lu: lda < n_pad + nrhs"); return BIEM_ERR_ARG; }
@@ -1026,6 +1063,9 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
   // (per call, not once per process: the attribute belongs to the current device)
   BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_inv_l11, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * NB * NB * sizeof(cplx))));
 
+  // BIEM_LDLT_PIVOT_REL (tests): acceptance threshold of the diagonal pivots; > 1 rejects every system
+  double nopiv = 0.0;
+  if (symmetric) { const char* e = getenv("BIEM_LDLT_PIVOT_REL"); nopiv = e ? atof(e) : NOPIV_REL; if (!(nopiv > 0.0)) nopiv = NOPIV_REL; }
   // factor the 64-column panel at column j, multipliers into P columns [pc, pc + NB)
   auto panel = [&](int j, int pc, bool in_workspace = false) {
     cplx* Pj = Pw + (size_t)pc * ldp;
@@ -1036,11 +1076,11 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     // strips in pairs: after the first strip only the second strip's 8 columns are updated (rank 8); the columns right of
     // the pair get both strips' updates as ONE rank-16 pass (336 instead of 504 column passes per panel through HBM)
     for (int c0 = 0; c0 < NB; c0 += 2 * PW) {
-      hipLaunchKernelGGL(k_panel_strip, dim3(nb), dim3(1024), strip_lds, st, Pj, ldp, p_stride, n_pad, j, c0, 0, d_ipiv, d_info);
+      hipLaunchKernelGGL(k_panel_strip, dim3(nb), dim3(1024), strip_lds, st, Pj, ldp, p_stride, n_pad, j, c0, 0, d_ipiv, d_info, nopiv);
       int below = n_pad - (j + c0 + PW);
       if (below > 0)
         hipLaunchKernelGGL(k_panel_update<PW>, dim3((below + 255) / 256, nb), dim3(256), 0, st, Pj, ldp, p_stride, n_pad, j, c0, PW);
-      hipLaunchKernelGGL(k_panel_strip, dim3(nb), dim3(1024), strip_lds, st, Pj, ldp, p_stride, n_pad, j, c0 + PW, 1, d_ipiv, d_info);
+      hipLaunchKernelGGL(k_panel_strip, dim3(nb), dim3(1024), strip_lds, st, Pj, ldp, p_stride, n_pad, j, c0 + PW, 1, d_ipiv, d_info, nopiv);
       below = n_pad - (j + c0 + 2 * PW);
       const int ncols = NB - (c0 + 2 * PW);
       if (ncols > 0 && below > 0)
@@ -1051,7 +1091,7 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     const int srows = keep_multipliers ? rows : (rows < NB ? rows : NB);
     hipLaunchKernelGGL(k_panel_store, dim3((srows + TR - 1) / TR, nb), dim3(256), 0, st, A, lda, sys_stride, Pj, ldp, p_stride,
                        keep_multipliers ? n_pad : j + srows, j);
-    if (pc > 0) hipLaunchKernelGGL(k_swap_p, dim3(nb), dim3(64), 0, st, Pw, ldp, p_stride, n_pad, j, pc, d_ipiv);
+    if (pc > 0 && !symmetric) hipLaunchKernelGGL(k_swap_p, dim3(nb), dim3(64), 0, st, Pw, ldp, p_stride, n_pad, j, pc, d_ipiv);
   };
   // the panel's row interchanges on the columns right of it
   auto swap_right = [&](int j) {
@@ -1062,8 +1102,9 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
   };
   // U row block: M[j:j+NB, j+NB:] <- L11^{-1} M[j:j+NB, j+NB:]
   cplx* Winv = Pw + (size_t)nb * p_stride;
-  auto trsm = [&](int j, int pc) {
-    const int rcols = n_cols - (j + NB);
+  auto trsm = [&](int j, int pc, int col_begin = -1) {
+    if (col_begin < 0) col_begin = j + NB;
+    const int rcols = n_cols - col_begin;
     if (rcols <= 0) return;
     const double work = 4.0 * (double)nb * NB * NB * rcols;
     {
@@ -1071,8 +1112,42 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
       hipLaunchKernelGGL(k_inv_l11, dim3(nb), dim3(64), 2 * NB * NB * sizeof(cplx), st, Pw + (size_t)pc * ldp, ldp, p_stride, j, Winv);
     }
     // A operand W[k][i], i = row - j: hand the kernel the base shifted by -j rows (only rows j .. j+63 are addressed)
-    launch_gemm_stream(st, nb, A, lda, sys_stride, Winv - j, NB, (long long)NB * NB, j, j + NB, j + NB, n_cols, j, NB, PK_TRSM, work);
+    launch_gemm_stream(st, nb, A, lda, sys_stride, Winv - j, NB, (long long)NB * NB, j, j + NB, col_begin, n_cols, j, NB, PK_TRSM, work);
   };
+  // symmetric path: the panel's U rows over the matrix columns by transposition, over the right-hand sides by the solve
+  auto u_rows_sym = [&](int j, int pc) {
+    const int rcols = n_pad - (j + NB);
+    if (rcols > 0) {
+      ProfScope ps(PK_TRSM, st, 0.0);
+      hipLaunchKernelGGL(k_u_from_l, dim3((rcols + 255) / 256, NB, nb), dim3(256), 0, st, A, lda, sys_stride, Pw + (size_t)pc * ldp, ldp, p_stride, n_pad, j);
+    }
+    trsm(j, pc, n_pad);
+  };
+
+  if (symmetric) {
+    // A = L D L^T without interchanges (the caller guarantees a complex-symmetric matrix; a rejected diagonal is reported in
+    // info).  Same four-panel groups and the same kernels; what changes: no interchanges; a panel's U rows are its transposed,
+    // D-scaled multipliers; only the right-hand-side columns of those rows take pending updates and the triangular solve; the
+    // K = 256 update runs over the lower triangle of tiles (and the right-hand sides): half the flops of the LU.
+    for (int J = 0; J < n_pad; J += 4 * NB) {
+      panel(J, 0); u_rows_sym(J, 0);
+      for (int q = 1; q < 4; ++q) {
+        const int jq = J + q * NB;
+        if (jq >= n_pad) break;
+        // the panel's columns: all pending updates of the group (K = 64 q) for all rows below, delivered into the workspace
+        launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, jq, n_pad, jq, jq + NB, J, q * NB, PK_OTHER, -1.0,
+                           Pw + (size_t)(q * NB) * ldp, ldp, p_stride, 0);
+        panel(jq, q * NB, true);
+        // right-hand sides of the panel's 64 rows: pending updates, then the solve; matrix columns: transposition
+        launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, jq, jq + NB, n_pad, n_cols, J, q * NB, PK_OTHER);
+        u_rows_sym(jq, q * NB);
+      }
+      if (J + 4 * NB >= n_pad) break;
+      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 4 * NB, n_pad, J + 4 * NB, n_pad, J, 4 * NB, PK_GEMM, -1.0,
+                         nullptr, 0, 0, 0, /*tri=*/1);
+      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 4 * NB, n_pad, n_pad, n_cols, J, 4 * NB, PK_OTHER);
+    }
+  } else
 
   {
     // three-level schedule.  Group = four 64-column panels a, b | c, d (workspace columns 0, 64 | 128, 192):

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <tuple>
 
 namespace biem {
 
@@ -108,6 +109,20 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
   make_labels(tree, n_end, p->labels, p->deg);
   make_labels(tree, p->n2, p->labels2, p->deg2);
   const int H = p->H, d = p->d, n = n_end;
+  {
+    // conjugate partners: conj Y_h = Y_p with the orders of all type-a nodes negated (every tree built here has real
+    // non-azimuthal factors and no sign: tests/test_oracle_golden.py::test_translation_block_matrix_is_complex_symmetric...)
+    std::map<std::tuple<int, int, int>, int> pos;
+    for (int h = 0; h < H; ++h) pos[std::make_tuple(p->labels[3 * h], p->labels[3 * h + 1], p->labels[3 * h + 2])] = h;
+    p->units.clear();
+    for (int h = 0; h < H; ++h) {
+      int a = p->labels[3 * h], b = p->labels[3 * h + 1], c = p->labels[3 * h + 2];
+      if (tree == TREE_A) a = -a; else if (tree == TREE_BA) b = -b; else if (tree == TREE_BBA) c = -c; else { b = -b; c = -c; }
+      auto it = pos.find(std::make_tuple(a, b, c));
+      if (it == pos.end()) { set_error("internal: harmonic %d has no conjugate partner", h); return BIEM_ERR_ARG; }
+      if (h <= it->second) { p->units.push_back(h); p->units.push_back(it->second); }
+    }
+  }
 
   // ---- boundary-data quadrature ----
   {
@@ -300,6 +315,7 @@ int plan_upload(biem_plan* p) {
   if ((rc = up(&p->d_deg, p->deg))) return rc;
   if ((rc = up(&p->d_labels2, p->labels2))) return rc;
   if ((rc = up(&p->d_deg2, p->deg2))) return rc;
+  if ((rc = up(&p->d_units, p->units))) return rc;
   if ((rc = up(&p->d_W, p->W))) return rc;
   if ((rc = up(&p->d_ptr, p->ptr))) return rc;
   if ((rc = up(&p->d_coef, p->coef))) return rc;
@@ -312,7 +328,7 @@ int plan_upload(biem_plan* p) {
 
 void plan_free(biem_plan* p) {
   if (p->device >= 0) {
-    (void)hipFree(p->d_labels); (void)hipFree(p->d_deg); (void)hipFree(p->d_labels2); (void)hipFree(p->d_deg2);
+    (void)hipFree(p->d_labels); (void)hipFree(p->d_deg); (void)hipFree(p->d_labels2); (void)hipFree(p->d_deg2); (void)hipFree(p->d_units);
     (void)hipFree(p->d_W); (void)hipFree(p->d_ptr); (void)hipFree(p->d_coef); (void)hipFree(p->d_tidx);
     (void)hipFree(p->d_tidx16); (void)hipFree(p->d_chunk_ent);
   }

@@ -12,6 +12,7 @@ struct biem_plan {
   // host tables
   std::vector<int> labels, deg;             // [H][3], [H]
   std::vector<int> labels2, deg2;           // [H2][3], [H2]
+  std::vector<int> units;                   // [U][2]: harmonics (h, p) with conj Y_h = Y_p, h <= p (h == p: real harmonic)
   std::vector<double> qy, qw;               // [Q][d], [Q]
   std::vector<double> W;                    // [Q][H] complex128 interleaved
   std::vector<uint32_t> ptr;                // [H*H + 1]
@@ -25,6 +26,7 @@ struct biem_plan {
   int device = -1;
   int* d_labels = nullptr; int* d_deg = nullptr;
   int* d_labels2 = nullptr; int* d_deg2 = nullptr;
+  int* d_units = nullptr;
   double* d_W = nullptr;
   uint32_t* d_ptr = nullptr; double* d_coef = nullptr; int32_t* d_tidx = nullptr;
   uint16_t* d_tidx16 = nullptr; int* d_chunk_ent = nullptr;

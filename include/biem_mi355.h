@@ -128,6 +128,15 @@ size_t biem_lu_workspace_bytes(int nb, int n_pad, int nrhs);
 int biem_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride,
                          int* d_ipiv /*[nb][n_pad]*/, int* d_info /*[nb]*/, void* d_work, size_t work_bytes, void* stream);
 
+/* Complex-SYMMETRIC systems (A = A^T, not Hermitian): A = L D L^T with the diagonal as pivots, no interchanges.  Same layout,
+ * workspace and kernels as biem_lu_factor_solve; a panel's U rows are its transposed multipliers and the K = 256 updates run
+ * over the lower triangle of tiles only (half the flops).  Only the lower triangle (and the diagonal 64 x 64 blocks) of A is
+ * read.  d_info[s] = -(row+1) when the diagonal entry at `row` was below 0.1 x the largest entry of its column (or NaN):
+ * the result of that system is not to be trusted and the caller re-solves it with biem_lu_factor_solve. */
+int biem_ldlt_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride,
+                           int* d_ipiv /*[nb][n_pad], identity on return*/, int* d_info /*[nb]*/, void* d_work, size_t work_bytes,
+                           void* stream);
+
 /* density[s][r][b][h] = x / (gh * blc): the reference's `density` from the equilibrated unknowns (also the
  * single-ball shortcut _biem.py:648-691 with x = f).  x element (s, r, i) at d_x[s*sys_stride + i*elem_stride + r*rhs_stride]. */
 int biem_density(const biem_plan* plan, int nb, int B, int nrhs, const double* d_x, long long sys_stride, long long elem_stride,
@@ -149,10 +158,20 @@ int biem_solve(const biem_plan* plan, int nb, int B, int nrhs, const double* d_k
                const double* d_radii, int geom_batched, const double* d_alpha, const double* d_beta, int ab_batched,
                const double* d_g, double* d_density, int* d_info, int chunk, void* d_work, size_t work_bytes, void* stream);
 
+/* The same through the complex-symmetric form of the system: with W the unitary map to real harmonics and
+ * R = diag(1/sqrt(gj gh)), R W^H M W R^-1 is complex symmetric (the reference solves the general system with LU,
+ * _biem.py:797; the symmetry is a property of (S|R), tests/test_oracle_golden.py).  Fill, symmetrise in place, L D L^T without
+ * interchanges, back-transform, density.  d_info[s] < 0: a diagonal pivot was rejected (see biem_ldlt_factor_solve) - the caller
+ * re-solves those systems with biem_solve.  Same arguments and workspace as biem_solve. */
+int biem_solve_ldlt(const biem_plan* plan, int nb, int B, int nrhs, const double* d_k /*c128*/, const double* d_eta,
+                    const double* d_centers, const double* d_radii, int geom_batched, const double* d_alpha, const double* d_beta,
+                    int ab_batched, const double* d_g, double* d_density, int* d_info, int chunk, void* d_work, size_t work_bytes,
+                    void* stream);
+
 /* ---- per-kernel-class timing with HIP events on the launch stream (thread-local; used by bench.py for the
  *      live `roofline` figures).  Between begin and end every launch of the calling thread is bracketed by two
  *      events; end synchronises on them and returns, per class, elapsed ms, algorithmic work and launch count.
- *      Classes: 0 tables, 1 fill (work = bytes written), 2 rhs, 3 panel, 4 swap, 5 trsm, 6 gemm = the K=256 trailing
+ *      Classes: 0 tables, 1 fill (work = bytes written), 2 rhs, 3 panel, 4 swap (LU row interchanges; symmetrising transform of the LDL^T path), 5 trsm, 6 gemm = the K=256 trailing
  *      updates of the four-panel groups (work = real flops, 8 per complex multiply-add), 7 back substitution, 8 the K=64 and
  *      K=128 updates inside a group. */
 #define BIEM_PROFILE_CLASSES 9

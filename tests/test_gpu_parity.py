@@ -534,3 +534,110 @@ def test_lu_solve_without_stored_factors(lib, N, nb, nrhs, monkeypatch):
     matrices (heavy pivoting across the panels of a four-panel group): the solution must not depend on it."""
     monkeypatch.setenv("BIEM_LU_DISCARD_FACTORS", "1")
     test_lu_factor_solve_vs_numpy(lib, N, nb, nrhs)
+
+
+# ---------------------------------------------------------------------------- complex-symmetric L D L^T path
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,nb,nrhs", [(64, 2, 1), (150, 2, 2), (256, 1, 1), (300, 3, 1), (576, 2, 3), (1000, 2, 1), (1345, 1, 2)])
+@pytest.mark.parametrize("discard", [False, True])
+def test_ldlt_factor_solve_vs_numpy(lib, N, nb, nrhs, discard, monkeypatch):
+    """biem_ldlt_factor_solve on complex-symmetric (not Hermitian) matrices I + E; only the lower triangle may be read: the
+    strict upper triangle outside the diagonal 64 x 64 blocks is filled with garbage."""
+    if discard:
+        monkeypatch.setenv("BIEM_LU_DISCARD_FACTORS", "1")
+    l, L = lib
+    rng = np.random.default_rng(N + 7)
+    npad = l.biem_lu_npad(N)
+    lda = npad + ((nrhs + 7) // 8) * 8
+    E = (rng.normal(size=(nb, N, N)) + 1j * rng.normal(size=(nb, N, N))) * (0.12 / np.sqrt(N))
+    As = np.eye(N)[None] * (1.0 + 0.2j) + E + np.swapaxes(E, 1, 2)
+    Fs = rng.normal(size=(nb, N, nrhs)) + 1j * rng.normal(size=(nb, N, nrhs))
+    A = np.zeros((nb, npad, lda), dtype=np.complex128)
+    A[:, :N, :N] = As
+    for i in range(N, npad):
+        A[:, i, i] = 1.0
+    blk = np.arange(npad) // 64
+    upper_off = (blk[:, None] < blk[None, :])
+    A[:, :npad, :npad][:, upper_off] = 1e30                    # must never be read
+    A[:, :N, npad:npad + nrhs] = Fs
+    dA = _dev(A, torch.complex128)
+    ipiv = torch.zeros((nb, npad), dtype=torch.int32, device="cuda")
+    info = torch.ones(nb, dtype=torch.int32, device="cuda")
+    wb = l.biem_lu_workspace_bytes(nb, npad, nrhs)
+    work = torch.empty(wb, dtype=torch.uint8, device="cuda")
+    L.check(l.biem_ldlt_factor_solve(nb, npad, nrhs, dA.data_ptr(), lda, npad * lda, ipiv.data_ptr(), info.data_ptr(), work.data_ptr(), wb, None))
+    torch.cuda.synchronize()
+    assert (info.cpu().numpy() == 0).all(), info.cpu().numpy()
+    X = dA.cpu().numpy()[:, :N, npad:npad + nrhs]
+    for s in range(nb):
+        Xo = np.linalg.solve(As[s], Fs[s])
+        assert np.abs(X[s] - Xo).max() / np.abs(Xo).max() < 1e-12, (N, s)
+
+
+@pytest.mark.gpu
+def test_ldlt_rejected_pivot_is_reported(lib):
+    l, L = lib
+    N = 128
+    A = np.zeros((2, N, N + 8), dtype=np.complex128)
+    A[:, :, :N] = np.eye(N)
+    A[1, 70, 70] = 0.01
+    A[1, 90, 70] = A[1, 70, 90] = 1.0                           # the diagonal is 1 % of its column's maximum
+    dA = _dev(A, torch.complex128)
+    ipiv = torch.zeros((2, N), dtype=torch.int32, device="cuda")
+    info = torch.zeros(2, dtype=torch.int32, device="cuda")
+    wb = l.biem_lu_workspace_bytes(2, N, 1)
+    work = torch.empty(wb, dtype=torch.uint8, device="cuda")
+    L.check(l.biem_ldlt_factor_solve(2, N, 1, dA.data_ptr(), N + 8, N * (N + 8), ipiv.data_ptr(), info.data_ptr(), work.data_ptr(), wb, None))
+    torch.cuda.synchronize()
+    assert info.cpu().tolist() == [0, -71]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tree,B,n_end", [("a", 4, 9), ("ba", 3, 7), ("bba", 2, 4), ("caa", 2, 4), ("bpa", 2, 5)])
+def test_ldlt_and_lu_paths_agree(amd, tree, B, n_end, monkeypatch):
+    """The symmetric path (default) and the pivoted LU (BIEM_SOLVER=lu, the reference's algorithm) give the same density."""
+    from biem_helmholtz_sphere_amd import _biem as impl
+
+    rng = np.random.default_rng(5)
+    c = amd.create_from_branching_types(tree)
+    d = c.c_ndim
+    cen, rad = _rand_geometry(rng, B, d)
+    ks = _dev(np.array([0.7, 2.9, 1.1 + 0.3j]), torch.complex128)
+    direction = rng.normal(size=d)
+    dirs = _dev(np.repeat(direction[:, None], 3, axis=1))
+    uin, ugr = amd.plane_wave(k=ks, direction=dirs)
+    out = {}
+    for solver in ("ldlt", "lu"):
+        monkeypatch.setenv("BIEM_SOLVER", solver)
+        calc = amd.biem(c, centers=_dev(cen)[None], radii=_dev(rad)[None], k=ks, eta=_dev(np.ones(3)), n_end=n_end, alpha=1.0 + 0.2j,
+                        beta=0.4, uin=uin, uin_grad=ugr)
+        out[solver] = calc.density.cpu().numpy()
+        st = dict(impl._last_solve_stats)
+        assert st == ({"ldlt_systems": 3, "lu_systems": 0} if solver == "ldlt" else {"ldlt_systems": 0, "lu_systems": 3}), st
+    scale = np.abs(out["lu"]) + 1e-12 * np.abs(out["lu"]).max()
+    assert np.max(np.abs(out["ldlt"] - out["lu"]) / scale) < 1e-9
+
+
+@pytest.mark.gpu
+def test_ldlt_near_a_resonance_and_forced_fallback(amd, monkeypatch):
+    """k rho = pi: j_0(k rho) = 0 to rounding and the symmetric scaling 1/sqrt(gj gh) is ~1e8 for degree 0 of that ball - the
+    symmetric matrix stays benign (that row of M is a unit row) and the result matches the oracle.  Then the fallback: with
+    the acceptance threshold above 1 every diagonal pivot is rejected and all systems are re-solved with the pivoted LU."""
+    from biem_helmholtz_sphere_amd import _biem as impl
+
+    cen = np.array([[0.0, 1.7, 0.1], [0.2, -1.6, 0.0]])
+    rad = np.array([1.0, 0.7])
+    ks = np.array([1.3, np.pi])
+    x = np.array([[4.0, 0.5, 0.2], [-3.0, 2.0, 1.0]])
+    c = amd.create_from_branching_types("ba")
+    dirs = np.zeros((3, 2)); dirs[0] = 1.0
+    uin, _ = amd.plane_wave(k=_dev(ks), direction=_dev(dirs))
+    uo = [O.uscat(O.solve_biem("ba", centers=cen, radii=rad, k=float(k), n_end=7, uin=O.plane_wave(float(k), [1.0, 0, 0])[0]), x) for k in ks]
+    for rel, stats in ((None, {"ldlt_systems": 2, "lu_systems": 0}), ("1.5", {"ldlt_systems": 2, "lu_systems": 2})):
+        if rel is not None:
+            monkeypatch.setenv("BIEM_LDLT_PIVOT_REL", rel)
+        calc = amd.biem(c, centers=_dev(cen)[None], radii=_dev(rad)[None], k=_dev(ks), eta=_dev(np.ones(2)), n_end=7, uin=uin)
+        assert impl._last_solve_stats == stats
+        u = calc.uscat(_dev(x.T.copy())).cpu().numpy()
+        for i in range(2):
+            assert np.abs(u[:, i] - uo[i]).max() / np.abs(uo[i]).max() < 1e-10

@@ -156,3 +156,32 @@ def test_eta_independence_and_robin_residual():
         dn_mid = dn  # first-order one-sided estimate is enough for a decay check
         errs.append(np.abs(alpha * ut + beta * (dn_mid + np.sum(ugr(xb) * y, axis=-1))).max())
     assert errs[1] < 1e-3 * max(errs[0], 1e-3) or errs[1] < 1e-4
+
+
+@pytest.mark.parametrize("name,d", [("a", 2), ("ba", 3), ("bba", 4), ("caa", 4)])
+def test_translation_block_matrix_is_complex_symmetric_up_to_conjugate_pairing(name, d):
+    """Structure the dense solve does not use yet: with P the signed permutation conj(Y_h) = sum_h' P[h, h'] Y_h'
+    (pairs (n, m) with (n, -m)), the block matrix G[(b,h),(b',h')] = (S|R)_{h'->h}(c_b - c_b') satisfies (G P)^T = G P.
+    The system (diag(gh/gj) + G) c = f / gj is then complex symmetric in the unknown y = P^T c, because diag(gh/gj) depends
+    on the degree only and commutes with P: an LDL^T factorisation would need half the flops of the LU."""
+    tr = O.tree(name)
+    n_end, k, B = 4, 1.3, 3
+    rng = np.random.default_rng(0)
+    cen = rng.normal(size=(B, d)) * 3
+    H = tr.n_harm(n_end)
+    G = np.zeros((B, H, B, H), dtype=np.complex128)
+    for b in range(B):
+        for bp in range(B):
+            if b != bp:
+                G[b, :, bp, :] = O.translation_SR(tr, n_end, k, cen[b] - cen[bp]).T
+    G = G.reshape(B * H, B * H)
+    u = rng.normal(size=(6 * H, d))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    Y = tr.harmonics(u, n_end)                          # [H, Q]
+    P1 = np.conj(Y) @ np.linalg.pinv(Y)
+    assert np.abs(np.abs(P1).sum(axis=1) - 1).max() < 1e-9      # a signed permutation
+    assert np.abs(P1 - P1.T).max() < 1e-9
+    deg = tr.degrees(n_end)
+    assert np.abs(P1[deg[:, None] != deg[None, :]]).max() < 1e-9   # inside one degree
+    S = G @ np.kron(np.eye(B), P1)
+    assert np.abs(S - S.T).max() < 1e-12 * np.abs(S).max()
