@@ -1034,6 +1034,55 @@ __global__ void k_zero_int(int* p, int n) {
   if (i < n) p[i] = 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// symmetric path, few right-hand sides: the forward elimination of the right-hand-side columns as matrix-vector work
+// (a 64 x 64 MFMA tile per 64 rows is almost empty for one column, and the triangular solve needs no inverse).
+// ---------------------------------------------------------------------------------------------
+// the 64 rows of the panel at column j (workspace columns pc ..): y = L11^{-1} (f - L[rows, 0:kd] y_prev), kd = pc = the columns
+// of the group's earlier panels (rows jg .. jg+kd).  One 64-thread workgroup per (system, right-hand side).
+__global__ void __launch_bounds__(64) k_rhs_panel(cplx* __restrict__ A, long long lda, long long sys_stride, const cplx* __restrict__ Pw,
+                                                   long long ldp, long long p_stride, int n_pad, int j, int jg, int pc) {
+  __shared__ cplx sy[4 * NB];
+  __shared__ cplx sx;
+  const int s = blockIdx.x, q = blockIdx.y, r = threadIdx.x;
+  cplx* F = A + (size_t)s * sys_stride + n_pad + q;
+  const cplx* Pr = Pw + (size_t)s * p_stride + j + r;            // row j + r of the workspace, column k at Pr[k * ldp]
+  for (int k = r; k < pc; k += NB) sy[k] = F[(size_t)(jg + k) * lda];
+  __syncthreads();
+  cplx y = F[(size_t)(j + r) * lda];
+  for (int k = 0; k < pc; ++k) y = cfnma(Pr[(size_t)k * ldp], sy[k], y);
+  for (int c = 0; c < NB - 1; ++c) {
+    if (r == c) sx = y;
+    __syncthreads();
+    if (r > c) y = cfnma(Pr[(size_t)(pc + c) * ldp], sx, y);
+    __syncthreads();
+  }
+  F[(size_t)(j + r) * lda] = y;
+}
+
+// rows below a group: f[i] -= L[i, 0:kd] y[jg : jg+kd]; one thread per row, the kd values of y in LDS
+__global__ void __launch_bounds__(256) k_rhs_update(cplx* __restrict__ A, long long lda, long long sys_stride, const cplx* __restrict__ Pw,
+                                                     long long ldp, long long p_stride, int n_pad, int row_begin, int jg, int kd) {
+  __shared__ cplx sy[4 * NB];
+  const int s = blockIdx.y, q = blockIdx.z;
+  cplx* F = A + (size_t)s * sys_stride + n_pad + q;
+  for (int k = threadIdx.x; k < kd; k += 256) sy[k] = F[(size_t)(jg + k) * lda];
+  __syncthreads();
+  const int i = row_begin + blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pad) return;
+  const cplx* Pr = Pw + (size_t)s * p_stride + i;
+  cplx a0 = make_double2(0.0, 0.0), a1 = a0, a2 = a0, a3 = a0;
+  for (int k = 0; k < kd; k += 4) {
+    a0 = cfma(Pr[(size_t)k * ldp], sy[k], a0);
+    a1 = cfma(Pr[(size_t)(k + 1) * ldp], sy[k + 1], a1);
+    a2 = cfma(Pr[(size_t)(k + 2) * ldp], sy[k + 2], a2);
+    a3 = cfma(Pr[(size_t)(k + 3) * ldp], sy[k + 3], a3);
+  }
+  cplx f = F[(size_t)i * lda];
+  f.x -= (a0.x + a1.x) + (a2.x + a3.x); f.y -= (a0.y + a1.y) + (a2.y + a3.y);
+  F[(size_t)i * lda] = f;
+}
+
 // U rows of a factored panel from its multipliers, symmetric path: U[j+i][c] = d_i L[c][i] for the columns c right of the panel
 // (A = L D L^T, so U = D L^T needs no triangular solve and no pending updates).  P is column-major: both sides are contiguous in c.
 __global__ void __launch_bounds__(256) k_u_from_l(cplx* __restrict__ A, long long lda, long long sys_stride, const cplx* __restrict__ Pj,
@@ -1115,13 +1164,20 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     launch_gemm_stream(st, nb, A, lda, sys_stride, Winv - j, NB, (long long)NB * NB, j, j + NB, col_begin, n_cols, j, NB, PK_TRSM, work);
   };
   // symmetric path: the panel's U rows over the matrix columns by transposition, over the right-hand sides by the solve
-  auto u_rows_sym = [&](int j, int pc) {
+  const bool rhs_gemv = nrhs > 0 && nrhs <= 8;   // few right-hand sides: matrix-vector kernels instead of nearly empty MFMA tiles
+  auto u_rows_sym = [&](int j, int jg, int pc) {
     const int rcols = n_pad - (j + NB);
     if (rcols > 0) {
       ProfScope ps(PK_TRSM, st, 0.0);
       hipLaunchKernelGGL(k_u_from_l, dim3((rcols + 255) / 256, NB, nb), dim3(256), 0, st, A, lda, sys_stride, Pw + (size_t)pc * ldp, ldp, p_stride, n_pad, j);
     }
-    trsm(j, pc, n_pad);
+    if (rhs_gemv) {
+      ProfScope ps(PK_TRSM, st, 0.0);
+      hipLaunchKernelGGL(k_rhs_panel, dim3(nb, nrhs), dim3(64), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, n_pad, j, jg, pc);
+    } else if (nrhs > 0) {
+      if (pc > 0) launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, j, j + NB, n_pad, n_cols, jg, pc, PK_OTHER);
+      trsm(j, pc, n_pad);
+    }
   };
 
   if (symmetric) {
@@ -1130,7 +1186,7 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     // D-scaled multipliers; only the right-hand-side columns of those rows take pending updates and the triangular solve; the
     // K = 256 update runs over the lower triangle of tiles (and the right-hand sides): half the flops of the LU.
     for (int J = 0; J < n_pad; J += 4 * NB) {
-      panel(J, 0); u_rows_sym(J, 0);
+      panel(J, 0); u_rows_sym(J, J, 0);
       for (int q = 1; q < 4; ++q) {
         const int jq = J + q * NB;
         if (jq >= n_pad) break;
@@ -1139,13 +1195,18 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
                            Pw + (size_t)(q * NB) * ldp, ldp, p_stride, 0);
         panel(jq, q * NB, true);
         // right-hand sides of the panel's 64 rows: pending updates, then the solve; matrix columns: transposition
-        launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, jq, jq + NB, n_pad, n_cols, J, q * NB, PK_OTHER);
-        u_rows_sym(jq, q * NB);
+        u_rows_sym(jq, J, q * NB);
       }
       if (J + 4 * NB >= n_pad) break;
       launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 4 * NB, n_pad, J + 4 * NB, n_pad, J, 4 * NB, PK_GEMM, -1.0,
                          nullptr, 0, 0, 0, /*tri=*/1);
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 4 * NB, n_pad, n_pad, n_cols, J, 4 * NB, PK_OTHER);
+      if (rhs_gemv) {
+        ProfScope ps(PK_OTHER, st, 0.0);
+        hipLaunchKernelGGL(k_rhs_update, dim3((n_pad - (J + 4 * NB) + 255) / 256, nb, nrhs), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp,
+                           p_stride, n_pad, J + 4 * NB, J, 4 * NB);
+      } else if (nrhs > 0) {
+        launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 4 * NB, n_pad, n_pad, n_cols, J, 4 * NB, PK_OTHER);
+      }
     }
   } else
 

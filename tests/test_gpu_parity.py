@@ -538,7 +538,7 @@ def test_lu_solve_without_stored_factors(lib, N, nb, nrhs, monkeypatch):
 
 # ---------------------------------------------------------------------------- complex-symmetric L D L^T path
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,nb,nrhs", [(64, 2, 1), (150, 2, 2), (256, 1, 1), (300, 3, 1), (576, 2, 3), (1000, 2, 1), (1345, 1, 2)])
+@pytest.mark.parametrize("N,nb,nrhs", [(64, 2, 1), (150, 2, 2), (256, 1, 1), (300, 3, 1), (576, 2, 3), (1000, 2, 1), (1345, 1, 2), (700, 2, 12)])
 @pytest.mark.parametrize("discard", [False, True])
 def test_ldlt_factor_solve_vs_numpy(lib, N, nb, nrhs, discard, monkeypatch):
     """biem_ldlt_factor_solve on complex-symmetric (not Hermitian) matrices I + E; only the lower triangle may be read: the
