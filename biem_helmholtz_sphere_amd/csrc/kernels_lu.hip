@@ -30,7 +30,9 @@ static inline long long ldp_of(int n_pad) { return (long long)n_pad; }
 size_t lu_workspace_bytes(int nb, int n_pad, int nrhs) {
   (void)nrhs;
   // four 64-column panels (two K = 128 blocks = one K = 256 update) + the 64 x 64 operand I - L11^{-1} of the MFMA triangular solve
-  return (size_t)nb * (4 * NB * (size_t)ldp_of(n_pad) + (size_t)NB * NB) * sizeof(cplx);
+  // + the tile map of the triangular (symmetric) update: one int per lower-triangle tile of the largest trailing matrix
+  const size_t T = (size_t)n_pad / NB;
+  return (size_t)nb * (4 * NB * (size_t)ldp_of(n_pad) + (size_t)NB * NB) * sizeof(cplx) + ((T * (T + 1) / 2 + 63) / 64) * 64 * sizeof(int);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -337,26 +339,38 @@ struct TileGrid {
   // column-major P[c][row]) instead of the matrix, which saves that panel's transposing load; pout == nullptr: off
   cplx* pout; long long pout_ld, pout_stride; int pcol_tx;
   int tri;                                      // 1: only tiles with tx <= ty (square region, symmetric update)
+  const int* tri_map; int tri_full;             // (ty << 16 | tx) of the first tri_full tiles of that order (the full bands)
 };
+
+// the triangular order: lower triangle incl. the diagonal tiles in bands of 8 tile rows; band b (tile rows 8b .. 8b+hb-1) holds
+// the columns 0 .. 8b+hb-1, column-major; column tx <= 8b has hb tiles, column 8b+q has hb-q.  A full band holds 64 b + 36
+// tiles, 32 b^2 + 4 b tiles precede it - independent of the matrix size, so ONE table serves every launch of a factorisation.
+__device__ __host__ inline void tri_decode_band(int r, int b, int hb, int& ty, int& tx) {
+  int rr = r - (32 * b * b + 4 * b);
+  if (rr < 8 * b * hb) { tx = rr / hb; ty = 8 * b + rr - tx * hb; }
+  else {
+    int rem = rr - 8 * b * hb, q = 0;
+    while (rem >= hb - q) { rem -= hb - q; ++q; }
+    tx = 8 * b + q; ty = 8 * b + q + rem;
+  }
+}
+__global__ void k_tri_map(int* map, int n) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  int b = (int)((sqrtf(16.0f + 128.0f * (float)r) - 4.0f) * (1.0f / 64.0f));
+  while (b > 0 && 32 * b * b + 4 * b > r) --b;
+  while (32 * (b + 1) * (b + 1) + 4 * (b + 1) <= r) ++b;
+  int ty, tx;
+  tri_decode_band(r, b, 8, ty, tx);
+  map[r] = ty << 16 | tx;
+}
 
 __device__ inline void tile_decode(const TileGrid& tg, int t, int& s, int& ty, int& tx) {
   s = t / tg.per_sys;
   int r = t - s * tg.per_sys;
   if (tg.tri) {
-    // lower triangle incl. the diagonal tiles, same band order: band b (tile rows 8b .. 8b+hb-1) holds the columns
-    // 0 .. 8b+hb-1; column tx <= 8b has hb tiles, column 8b+q has hb-q.  Full bands hold 64 b + 36 tiles, 32 b^2 + 4 b before.
-    int b = (int)((sqrtf(16.0f + 128.0f * (float)r) - 4.0f) * (1.0f / 64.0f));
-    if (b > tg.full_bands) b = tg.full_bands;
-    while (b > 0 && 32 * b * b + 4 * b > r) --b;
-    while (b < tg.full_bands && 32 * (b + 1) * (b + 1) + 4 * (b + 1) <= r) ++b;
-    const int hb = (b < tg.full_bands) ? 8 : tg.ty_n - 8 * tg.full_bands;
-    int rr = r - (32 * b * b + 4 * b);
-    if (rr < 8 * b * hb) { tx = rr / hb; ty = 8 * b + rr - tx * hb; }
-    else {
-      int rem = rr - 8 * b * hb, q = 0;
-      while (rem >= hb - q) { rem -= hb - q; ++q; }
-      tx = 8 * b + q; ty = 8 * b + q + rem;
-    }
+    if (r < tg.tri_full) { const int v = tg.tri_map[r]; ty = v >> 16; tx = v & 0xffff; }
+    else tri_decode_band(r, tg.full_bands, tg.ty_n - 8 * tg.full_bands, ty, tx);      // the partial last band
     return;
   }
   int fb = tg.full_bands * 8 * tg.tx_n;
@@ -913,13 +927,15 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
 static void launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, long long sys_stride, const cplx* Pw, long long ldp,
                                long long p_stride, int row_begin, int row_end, int col_begin, int col_end, int brow, int kd,
                                int prof_class = PK_GEMM, double prof_work = -1.0, cplx* pout = nullptr, long long pout_ld = 0,
-                               long long pout_stride = 0, int pcol_tx = 0, int tri = 0) {
+                               long long pout_stride = 0, int pcol_tx = 0, const int* tri_map = nullptr) {
+  const int tri = tri_map != nullptr;
   const int rrows = row_end - row_begin, rcols = col_end - col_begin;
   if (rrows <= 0 || rcols <= 0) return;
   TileGrid tg;
   tg.pout = pout; tg.pout_ld = pout_ld; tg.pout_stride = pout_stride; tg.pcol_tx = pcol_tx; tg.tri = tri;
   tg.ty_n = (rrows + BM3 - 1) / BM3; tg.tx_n = (rcols + BN3 - 1) / BN3;
   tg.per_sys = tri ? tg.ty_n * (tg.ty_n + 1) / 2 : tg.ty_n * tg.tx_n; tg.full_bands = tg.ty_n / 8; tg.ntiles = tg.per_sys * nb;
+  tg.tri_map = tri_map; tg.tri_full = 32 * tg.full_bands * tg.full_bands + 4 * tg.full_bands;
   tg.row_begin = row_begin; tg.row_end = row_end; tg.col_begin = col_begin; tg.col_end = col_end; tg.brow = brow;
   const int cap = 512;                         // persistent grid: 2 workgroups per CU
   int want = (tg.ntiles + 7) / 8 * 8;          // one workgroup per tile up to the cap, multiple of 8
@@ -1181,6 +1197,12 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
   };
 
   if (symmetric) {
+    // the tile map of the triangular updates (full bands of the largest trailing matrix), behind the panels and W
+    int* tri_map = (int*)(Winv + (size_t)nb * NB * NB);
+    {
+      const int T = n_pad / NB, fb = T / 8, n_map = 32 * fb * fb + 4 * fb;
+      if (n_map > 0) hipLaunchKernelGGL(k_tri_map, dim3((n_map + 255) / 256), dim3(256), 0, st, tri_map, n_map);
+    }
     // A = L D L^T without interchanges (the caller guarantees a complex-symmetric matrix; a rejected diagonal is reported in
     // info).  Same four-panel groups and the same kernels; what changes: no interchanges; a panel's U rows are its transposed,
     // D-scaled multipliers; only the right-hand-side columns of those rows take pending updates and the triangular solve; the
@@ -1199,7 +1221,7 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
       }
       if (J + 4 * NB >= n_pad) break;
       launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 4 * NB, n_pad, J + 4 * NB, n_pad, J, 4 * NB, PK_GEMM, -1.0,
-                         nullptr, 0, 0, 0, /*tri=*/1);
+                         nullptr, 0, 0, 0, tri_map);
       if (rhs_gemv) {
         ProfScope ps(PK_OTHER, st, 0.0);
         hipLaunchKernelGGL(k_rhs_update, dim3((n_pad - (J + 4 * NB) + 255) / 256, nb, nrhs), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp,
