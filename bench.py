@@ -5,7 +5,8 @@ Workload (BASELINE.json configs[2], the one the metric is quoted on; it fits one
     d=3 ('ba'), n_balls=16 on the 4x4 grid {-6,-2,2,6}^2 x {0} (reference cli.py:170-185 `_center(2,3)`), radius 1,
     n_end=20 (N = 6400 unknowns per system), sound-soft, eta=1, plane wave along +x0 with the system's own k,
     batch of wavenumbers k in [0.5, 8].
-One *step* = one pass of the whole hot path (boundary samples -> RHS projection -> fill -> LU -> density) over this
+One *step* = one pass of the whole hot path (boundary samples -> RHS projection -> fill -> symmetrise -> L D L^T (pivoted LU
+for systems whose diagonal pivots are rejected; BIEM_SOLVER=lu: LU for all) -> density) over this
 rank's shard of the batch through the public `biem()` API; inputs are resident in HBM when the clock starts, the
 densities are resident in HBM when it stops.  Weak scaling: every GPU owns `--systems-per-gpu` systems (default 256 =
 the whole 256-wavenumber batch of the config, which fits one MI355X: 256 x 656 MB of matrices); the k's of the whole job
@@ -106,6 +107,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
     import biem_helmholtz_sphere_amd as amd
+    from biem_helmholtz_sphere_amd import _biem as impl
     from biem_helmholtz_sphere_amd import _lib as L
 
     lib = L.load()
@@ -200,12 +202,17 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"cfg3: d=3 'ba', n_balls=16 (4x4 grid, pitch 4), n_end={args.n_end}, N={N}, sound-soft, "
                                f"{per_gpu} wavenumbers per GPU from linspace(0.5, 8, {per_gpu * world})",
-                   "systems_per_gpu": per_gpu, "parallelism": f"batch-shard x{world}"},
+                   "systems_per_gpu": per_gpu, "parallelism": f"batch-shard x{world}",
+                   "solver": os.environ.get("BIEM_SOLVER", "ldlt"), "solved_by": dict(impl._last_solve_stats)},
         "max_rel_err_uscat": relerr,
         "roofline": {
-            "bound": "mfma", "kernel": "k_gemm3m_pipe<256> (zgemm3m trailing update of a four-panel group, v_mfma_f64_4x4x4_4b_f64)",
+            "bound": "mfma", "kernel": "k_gemm3m_pipe<256> (zgemm3m K=256 trailing update of a four-panel group, v_mfma_f64_4x4x4_4b_f64; lower-triangle tiles in the L D L^T path)",
             "achieved": gemm_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": (gemm_tflops / FP64_MFMA_PEAK_TFLOPS) if gemm_tflops else None,
+            # `achieved` counts the ALGORITHMIC 8 real flops per complex multiply-add; the 3M form issues 6 of them as MFMAs
+            # (3 real products instead of 4), so the matrix pipe itself runs at 3/4 of `achieved`:
+            "mfma_issued_tflops": 0.75 * gemm_tflops if gemm_tflops else None,
+            "mfma_issued_frac": (0.75 * gemm_tflops / FP64_MFMA_PEAK_TFLOPS) if gemm_tflops else None,
             "traffic": traffic,
             "avg_launch_ms": ms[gi] / launches[gi] if launches[gi] else None,
             "lu_effective_tflops": lu_flops * per_gpu * args.steps / (sum(ms[3:9]) * 1e-3) / 1e12 if sum(ms[3:9]) > 0 else None,
