@@ -412,6 +412,9 @@ __global__ void __launch_bounds__(256) k_symmetrize(int H, int U, int n_end, int
     ch = bc * H + units[2 * uc]; cp = bc * H + units[2 * uc + 1];
     scale = cmul(rr, zsqrt(cmul(ts[(size_t)bc * 3 * n_end + deg[units[2 * uc]]], ts[(size_t)bc * 3 * n_end + n_end + deg[units[2 * uc]]])));   // r_row / r_col
   } else { ch = cp = n_pad + (cu - B * U); scale = rr; }
+  // the L D L^T factorisation reads only the lower triangle and the diagonal 64 x 64 blocks: blocks wholly right of their
+  // rows' diagonal blocks are neither transformed nor written (their memory keeps the untransformed M; never read)
+  if (cu < B * U && (ch < cp ? ch : cp) >= ((br * H + (rh > rp ? rh : rp)) / 64 + 1) * 64) return;
   cplx x00 = row_h[ch], x01 = row_h[cp], x10 = x00, x11 = x01;
   if (rp != rh) { x10 = row_p[ch]; x11 = row_p[cp]; }
   if (rp != rh) {   // rows: (h + p)/sqrt2, i (h - p)/sqrt2
