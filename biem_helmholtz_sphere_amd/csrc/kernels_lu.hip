@@ -91,7 +91,7 @@ constexpr int STRIP_CACHE_ROWS = 1024;   // rows of the strip kept in LDS (one p
 
 __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, long long ldp, long long p_stride, int n_pad, int j, int c0,
                                                        int second, int* __restrict__ ipiv, int* __restrict__ info, double nopiv_rel) {
-  // nopiv_rel > 0 (symmetric LDL^T path): the pivot is the diagonal entry; the column maximum is still searched and a diagonal
+  // nopiv_rel > 0 (no-interchange mode; the symmetric path now uses k_diag_nopiv / k_panel_l21 instead): the pivot is the diagonal entry; the column maximum is still searched and a diagonal
   // below nopiv_rel times it marks the system (info = -(row + 1)) so that the caller can redo it with the pivoted factorisation.
   const bool nopiv = nopiv_rel > 0.0;
   // Thread t owns the fixed rows rs + t + 1024 k of the strip (rs = j + c0).  Its first row (k = 0) lives in LDS for the whole
@@ -1099,6 +1099,98 @@ __global__ void __launch_bounds__(256) k_rhs_update(cplx* __restrict__ A, long l
   F[(size_t)i * lda] = f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// panel factorisation without interchanges (symmetric path): the 64 x 64 diagonal block is factored by one workgroup per
+// system (k_diag_nopiv, which also forms X = U11^{-1}); the rows below are L21 = A21 X, one thread per row over all CUs
+// (k_panel_l21): 160 column passes per panel through HBM instead of the strips' 576, no per-column barriers.
+// The acceptance test of the pivoted-path strips carries over unchanged: |pivot| >= rel * max |column below, updated| is
+// |l_ic| <= 1 / rel for every multiplier; a violation marks the system (info = -(row + 1) of the panel's first row).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_diag_nopiv(cplx* __restrict__ Pj, long long ldp, long long p_stride, int n_pad, int j,
+                                                    cplx* __restrict__ Xinv, int* __restrict__ ipiv, int* __restrict__ info, double rel) {
+  __shared__ cplx a[NB][NB + 1];     // a[c][r]: column c, row r (as in the workspace)
+  __shared__ cplx x[NB][NB + 1];     // x[k][c] = (U11^{-1})[k][c]
+  __shared__ int bad;
+  const int s = blockIdx.x, r = threadIdx.x;
+  cplx* Ps = Pj + (size_t)s * p_stride + j;
+  if (r == 0) bad = 0;
+  for (int c = 0; c < NB; ++c) a[c][r] = Ps[(size_t)c * ldp + r];
+  ipiv[(size_t)s * n_pad + j + r] = j + r;
+  __syncthreads();
+  for (int c = 0; c < NB; ++c) {
+    const cplx piv = a[c][c];
+    const double pa = fabs(piv.x) + fabs(piv.y);
+    if (r > c) {
+      const cplx v = a[c][r];
+      if (!(pa >= rel * (fabs(v.x) + fabs(v.y)))) bad = 1;
+      const cplx l = cmul(v, crecip(piv));
+      a[c][r] = l;
+      for (int c2 = c + 1; c2 < NB; ++c2) a[c2][r] = cfnma(l, a[c2][c], a[c2][r]);
+    } else if (r == c && !(pa > 0.0)) bad = 1;
+    __syncthreads();
+  }
+  // thread r = column r of X: back substitution U X = I
+  {
+    const int c = r;
+#pragma unroll 1
+    for (int k = c; k >= 0; --k) {
+      cplx acc = (k == c) ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
+      for (int m = k + 1; m <= c; ++m) acc = cfnma(a[m][k], x[m][c], acc);
+      const cplx v = cmul(acc, crecip(a[k][k]));
+      x[k][c] = v;
+    }
+    for (int k = c + 1; k < NB; ++k) x[k][c] = make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  for (int c = 0; c < NB; ++c) Ps[(size_t)c * ldp + r] = a[c][r];
+  cplx* Xo = Xinv + (size_t)s * NB * NB;
+  for (int k = 0; k < NB; ++k) Xo[k * NB + r] = x[k][r];
+  if (r == 0 && bad && info[s] == 0) info[s] = -(j + 1);
+}
+
+__global__ void __launch_bounds__(256) k_panel_l21(cplx* __restrict__ Pj, long long ldp, long long p_stride, int n_pad, int j,
+                                                    const cplx* __restrict__ Xinv, int* __restrict__ info, double rel) {
+  extern __shared__ cplx sX[];       // [k][c], 64 x 64
+  const int s = blockIdx.y, tid = threadIdx.x;
+  const cplx* Xs = Xinv + (size_t)s * NB * NB;
+  for (int e = tid; e < NB * NB; e += 256) sX[e] = Xs[e];
+  __syncthreads();
+  const int i = j + NB + blockIdx.x * 256 + tid;
+  if (i >= n_pad) return;
+  cplx* Pr = Pj + (size_t)s * p_stride + i;
+  double lmax = 0.0;
+  // columns 32..63 first (they need a_0..a_63 and overwrite a_32..a_63), then 0..31 (a_0..a_31 only)
+#pragma unroll 1
+  for (int half = 1; half >= 0; --half) {
+    const int cb = half * 32;
+    cplx acc[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) acc[q] = make_double2(0.0, 0.0);
+    if (half) {
+#pragma unroll 4
+      for (int k = 0; k < 32; ++k) {            // full 32 columns
+        const cplx ak = Pr[(size_t)k * ldp];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) acc[q] = cfma(ak, sX[k * NB + cb + q], acc[q]);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {            // triangular part: X[k][c] = 0 for c < k
+      const cplx ak = Pr[(size_t)(cb + kk) * ldp];
+#pragma unroll
+      for (int q = 0; q < 32; ++q)
+        if (q >= kk) acc[q] = cfma(ak, sX[(cb + kk) * NB + cb + q], acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      Pr[(size_t)(cb + q) * ldp] = acc[q];
+      const double v = fabs(acc[q].x) + fabs(acc[q].y);
+      lmax = v > lmax ? v : lmax;
+    }
+  }
+  if (!(lmax * rel <= 1.0) && info[s] == 0) info[s] = -(j + 1);
+}
+
 // U rows of a factored panel from its multipliers, symmetric path: U[j+i][c] = d_i L[c][i] for the columns c right of the panel
 // (A = L D L^T, so U = D L^T needs no triangular solve and no pending updates).  P is column-major: both sides are contiguous in c.
 __global__ void __launch_bounds__(256) k_u_from_l(cplx* __restrict__ A, long long lda, long long sys_stride, const cplx* __restrict__ Pj,
@@ -1127,8 +1219,10 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
   BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_panel_strip, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds));
   // (per call, not once per process: the attribute belongs to the current device)
   BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_inv_l11, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * NB * NB * sizeof(cplx))));
+  BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_panel_l21, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NB * NB * sizeof(cplx))));
 
-  // BIEM_LDLT_PIVOT_REL (tests): acceptance threshold of the diagonal pivots; > 1 rejects every system
+  cplx* Winv = Pw + (size_t)nb * p_stride;      // 64 x 64 per system: I - L11^{-1} (LU) / U11^{-1} (symmetric path)
+  // BIEM_LDLT_PIVOT_REL (tests): acceptance threshold of the diagonal pivots (multipliers <= 1 / threshold); 1e30 rejects every system
   double nopiv = 0.0;
   if (symmetric) { const char* e = getenv("BIEM_LDLT_PIVOT_REL"); nopiv = e ? atof(e) : NOPIV_REL; if (!(nopiv > 0.0)) nopiv = NOPIV_REL; }
   // factor the 64-column panel at column j, multipliers into P columns [pc, pc + NB)
@@ -1138,6 +1232,13 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     ProfScope ps(PK_PANEL, st, 4.0 * (double)nb * rows * NB * NB);
     if (!in_workspace)     // (panels b, c, d of a group arrive in the workspace straight from the update that produced them)
       hipLaunchKernelGGL(k_panel_load, dim3((rows + TR - 1) / TR, nb), dim3(256), 0, st, A, lda, sys_stride, Pj, ldp, p_stride, n_pad, j);
+    if (symmetric) {
+      // no interchanges: diagonal block in one workgroup per system, then L21 = A21 U11^{-1} over all CUs
+      hipLaunchKernelGGL(k_diag_nopiv, dim3(nb), dim3(64), 0, st, Pj, ldp, p_stride, n_pad, j, Winv, d_ipiv, d_info, nopiv);
+      if (rows > NB)
+        hipLaunchKernelGGL(k_panel_l21, dim3((rows - NB + 255) / 256, nb), dim3(256), NB * NB * sizeof(cplx), st, Pj, ldp, p_stride, n_pad, j,
+                           Winv, d_info, nopiv);
+    } else
     // strips in pairs: after the first strip only the second strip's 8 columns are updated (rank 8); the columns right of
     // the pair get both strips' updates as ONE rank-16 pass (336 instead of 504 column passes per panel through HBM)
     for (int c0 = 0; c0 < NB; c0 += 2 * PW) {
@@ -1166,7 +1267,6 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     hipLaunchKernelGGL(k_swap, dim3((rcols + 255) / 256, nb), dim3(256), 0, st, A, lda, sys_stride, n_pad, n_cols, j, d_ipiv, 0);
   };
   // U row block: M[j:j+NB, j+NB:] <- L11^{-1} M[j:j+NB, j+NB:]
-  cplx* Winv = Pw + (size_t)nb * p_stride;
   auto trsm = [&](int j, int pc, int col_begin = -1) {
     if (col_begin < 0) col_begin = j + NB;
     const int rcols = n_cols - col_begin;
