@@ -185,7 +185,8 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
     if os.path.exists(tpath) and args.n_end == 20:
         with open(tpath) as f:
-            traffic = json.load(f)["bytes_per_launch_per_system"] * per_gpu
+            tj = json.load(f)
+            traffic = tj["bytes_per_launch_per_system" if os.environ.get("BIEM_SOLVER", "ldlt") == "ldlt" else "bytes_per_launch_per_system_lu"] * per_gpu
 
     out = {
         "metric": "BIEM systems solved/sec + max |u_scat| rel-err vs NumPy ref",
