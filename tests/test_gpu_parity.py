@@ -496,8 +496,10 @@ def test_many_small_systems_are_chunked(amd):
         assert abs(u[i] - O.uscat(res, np.zeros((1, 3)))[0]) < 1e-11 * abs(u[i]), i
 
 
-def test_batched_geometry_and_points_per_system(amd):
-    """Geometry that differs between systems (centers [K, B, d], radii [K, B]) and evaluation points given per system
+@pytest.mark.parametrize("force_lu_fallback", [False, True])
+def test_batched_geometry_and_points_per_system(amd, force_lu_fallback, monkeypatch):
+    """(force_lu_fallback: every system is rejected by the symmetric path and re-solved by the pivoted LU from gathered
+    per-system geometry.)  Geometry that differs between systems (centers [K, B, d], radii [K, B]) and evaluation points given per system
     (expand_x=False: x of shape (d, P, K)); every system against its own oracle solve."""
     c = amd.create_from_branching_types("ba")
     rng = np.random.default_rng(5)
@@ -507,7 +509,11 @@ def test_batched_geometry_and_points_per_system(amd):
     ks = np.array([1.1, 1.9, 2.6])
     dirs = np.zeros((3, K)); dirs[1] = 1.0
     uin, ugr = amd.plane_wave(k=_dev(ks), direction=_dev(dirs))
+    if force_lu_fallback:
+        monkeypatch.setenv("BIEM_LDLT_PIVOT_REL", "1e30")
     calc = amd.biem(c, centers=_dev(cen), radii=_dev(rad), k=_dev(ks), n_end=8, alpha=0.0, beta=1.0, uin=uin, uin_grad=ugr)
+    from biem_helmholtz_sphere_amd import _biem as impl
+    assert impl._last_solve_stats == {"ldlt_systems": K, "lu_systems": K if force_lu_fallback else 0}
     xs = 6.0 + rng.normal(size=(K, 4, 3))                               # [K, P, d]
     u = calc.uscat(_dev(np.transpose(xs, (2, 1, 0))), expand_x=False).cpu().numpy()      # (d, P, K) -> [P, K]
     assert u.shape == (4, K)
