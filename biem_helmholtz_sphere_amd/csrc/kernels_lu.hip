@@ -1106,46 +1106,56 @@ __global__ void __launch_bounds__(256) k_rhs_update(cplx* __restrict__ A, long l
 // The acceptance test of the pivoted-path strips carries over unchanged: |pivot| >= rel * max |column below, updated| is
 // |l_ic| <= 1 / rel for every multiplier; a violation marks the system (info = -(row + 1) of the panel's first row).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_diag_nopiv(cplx* __restrict__ Pj, long long ldp, long long p_stride, int n_pad, int j,
-                                                    cplx* __restrict__ Xinv, int* __restrict__ ipiv, int* __restrict__ info, double rel) {
+__global__ void __launch_bounds__(256) k_diag_nopiv(cplx* __restrict__ Pj, long long ldp, long long p_stride, int n_pad, int j,
+                                                     cplx* __restrict__ Xinv, int* __restrict__ ipiv, int* __restrict__ info, double rel) {
+  // 256 threads: row r = tid & 63, part = tid >> 6 (one wave each).  Elimination: the four parts share the trailing columns of a
+  // step (c2 = c+1+part, +4, ...).  Inverse: X = U11^{-1} by anti-diagonals d = c - k (entries of one d are independent), the
+  // sum over m of an entry split over the four parts and reduced through LDS.
   __shared__ cplx a[NB][NB + 1];     // a[c][r]: column c, row r (as in the workspace)
   __shared__ cplx x[NB][NB + 1];     // x[k][c] = (U11^{-1})[k][c]
+  __shared__ cplx red[4][NB];
   __shared__ int bad;
-  const int s = blockIdx.x, r = threadIdx.x;
+  const int s = blockIdx.x, tid = threadIdx.x, r = tid & 63, part = tid >> 6;
   cplx* Ps = Pj + (size_t)s * p_stride + j;
-  if (r == 0) bad = 0;
-  for (int c = 0; c < NB; ++c) a[c][r] = Ps[(size_t)c * ldp + r];
-  ipiv[(size_t)s * n_pad + j + r] = j + r;
+  if (tid == 0) bad = 0;
+  for (int c = part; c < NB; c += 4) { a[c][r] = Ps[(size_t)c * ldp + r]; x[c][r] = make_double2(0.0, 0.0); }
+  if (part == 0) ipiv[(size_t)s * n_pad + j + r] = j + r;
   __syncthreads();
   for (int c = 0; c < NB; ++c) {
     const cplx piv = a[c][c];
     const double pa = fabs(piv.x) + fabs(piv.y);
+    cplx l = make_double2(0.0, 0.0);
     if (r > c) {
       const cplx v = a[c][r];
-      if (!(pa >= rel * (fabs(v.x) + fabs(v.y)))) bad = 1;
-      const cplx l = cmul(v, crecip(piv));
-      a[c][r] = l;
-      for (int c2 = c + 1; c2 < NB; ++c2) a[c2][r] = cfnma(l, a[c2][c], a[c2][r]);
-    } else if (r == c && !(pa > 0.0)) bad = 1;
-    __syncthreads();
-  }
-  // thread r = column r of X: back substitution U X = I
-  {
-    const int c = r;
-#pragma unroll 1
-    for (int k = c; k >= 0; --k) {
-      cplx acc = (k == c) ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
-      for (int m = k + 1; m <= c; ++m) acc = cfnma(a[m][k], x[m][c], acc);
-      const cplx v = cmul(acc, crecip(a[k][k]));
-      x[k][c] = v;
-    }
-    for (int k = c + 1; k < NB; ++k) x[k][c] = make_double2(0.0, 0.0);
+      if (part == 0 && !(pa >= rel * (fabs(v.x) + fabs(v.y)))) bad = 1;
+      l = cmul(v, crecip(piv));
+      for (int c2 = c + 1 + part; c2 < NB; c2 += 4) a[c2][r] = cfnma(l, a[c2][c], a[c2][r]);
+    } else if (r == c && part == 0 && !(pa > 0.0)) bad = 1;
+    __syncthreads();                       // every part has read a[c][r]; the trailing columns are updated
+    if (r > c && part == 0) a[c][r] = l;   // column c is not read again inside this loop
   }
   __syncthreads();
-  for (int c = 0; c < NB; ++c) Ps[(size_t)c * ldp + r] = a[c][r];
+  // X: thread (k = r, part) works on the entry (k, k + d) of anti-diagonal d
+  for (int d = 0; d < NB; ++d) {
+    const int k = r, c = r + d;
+    cplx acc = make_double2(0.0, 0.0);
+    if (c < NB)
+      for (int m = k + 1 + part; m <= c; m += 4) acc = cfma(a[m][k], x[m][c], acc);     // U[k][m] x[m][c]
+    red[part][r] = acc;
+    __syncthreads();
+    if (part == 0 && c < NB) {
+      cplx sum = red[0][r];
+      sum.x += red[1][r].x + red[2][r].x + red[3][r].x; sum.y += red[1][r].y + red[2][r].y + red[3][r].y;
+      cplx rhs = (d == 0) ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
+      rhs.x -= sum.x; rhs.y -= sum.y;
+      x[k][c] = cmul(rhs, crecip(a[k][k]));
+    }
+    __syncthreads();
+  }
+  for (int c = part; c < NB; c += 4) Ps[(size_t)c * ldp + r] = a[c][r];
   cplx* Xo = Xinv + (size_t)s * NB * NB;
-  for (int k = 0; k < NB; ++k) Xo[k * NB + r] = x[k][r];
-  if (r == 0 && bad && info[s] == 0) info[s] = -(j + 1);
+  for (int k = part; k < NB; k += 4) Xo[k * NB + r] = x[k][r];
+  if (tid == 0 && bad && info[s] == 0) info[s] = -(j + 1);
 }
 
 __global__ void __launch_bounds__(256) k_panel_l21(cplx* __restrict__ Pj, long long ldp, long long p_stride, int n_pad, int j,
@@ -1234,7 +1244,7 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
       hipLaunchKernelGGL(k_panel_load, dim3((rows + TR - 1) / TR, nb), dim3(256), 0, st, A, lda, sys_stride, Pj, ldp, p_stride, n_pad, j);
     if (symmetric) {
       // no interchanges: diagonal block in one workgroup per system, then L21 = A21 U11^{-1} over all CUs
-      hipLaunchKernelGGL(k_diag_nopiv, dim3(nb), dim3(64), 0, st, Pj, ldp, p_stride, n_pad, j, Winv, d_ipiv, d_info, nopiv);
+      hipLaunchKernelGGL(k_diag_nopiv, dim3(nb), dim3(256), 0, st, Pj, ldp, p_stride, n_pad, j, Winv, d_ipiv, d_info, nopiv);
       if (rows > NB)
         hipLaunchKernelGGL(k_panel_l21, dim3((rows - NB + 255) / 256, nb), dim3(256), NB * NB * sizeof(cplx), st, Pj, ldp, p_stride, n_pad, j,
                            Winv, d_info, nopiv);
