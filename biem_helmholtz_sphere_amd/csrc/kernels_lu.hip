@@ -86,14 +86,11 @@ __global__ void __launch_bounds__(256) k_panel_store(cplx* __restrict__ A, long 
 // ---------------------------------------------------------------------------------------------
 constexpr int PW = 8;
 
-constexpr double NOPIV_REL = 0.1;        // no-pivot path: smallest accepted |diagonal| / column maximum (element growth <= 11 per step)
+constexpr double NOPIV_REL = 0.1;        // symmetric path: smallest accepted |diagonal| / |entry below it| (multipliers <= 10)
 constexpr int STRIP_CACHE_ROWS = 1024;   // rows of the strip kept in LDS (one per thread): 1024 x 8 x 16 B = 128 KiB
 
 __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, long long ldp, long long p_stride, int n_pad, int j, int c0,
-                                                       int second, int* __restrict__ ipiv, int* __restrict__ info, double nopiv_rel) {
-  // nopiv_rel > 0 (no-interchange mode; the symmetric path now uses k_diag_nopiv / k_panel_l21 instead): the pivot is the diagonal entry; the column maximum is still searched and a diagonal
-  // below nopiv_rel times it marks the system (info = -(row + 1)) so that the caller can redo it with the pivoted factorisation.
-  const bool nopiv = nopiv_rel > 0.0;
+                                                       int second, int* __restrict__ ipiv, int* __restrict__ info) {
   // Thread t owns the fixed rows rs + t + 1024 k of the strip (rs = j + c0).  Its first row (k = 0) lives in LDS for the whole
   // strip - the strip is read and written once per column pass otherwise, and with every CU running one system's strip the
   // kernel is bound by that traffic (6.5 TB/s at 256 systems); the upper rows are the ones every pass touches longest.
@@ -122,13 +119,11 @@ __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, lon
     }
     if (lane == 0) { sval[buf][wave] = best; sidx[buf][wave] = bi; }
   };
-  double colmax = 0.0;                          // the searched column's maximum (cabs1), for the no-pivot check
   auto decide = [&](int buf, int r0) -> int {   // every thread reduces the 16 candidates redundantly (no extra barrier)
     double b = sval[buf][0]; int ix = sidx[buf][0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) { double v = sval[buf][w]; int i2 = sidx[buf][w]; if (v > b || (v == b && i2 < ix)) { b = v; ix = i2; } }
-    colmax = b;
-    return (ix == 0x7fffffff || nopiv) ? r0 : ix;          // all-NaN column: keep the diagonal
+    return ix == 0x7fffffff ? r0 : ix;          // all-NaN column: keep the diagonal
   };
 
   {  // stage the cached rows and search the strip's first column
@@ -173,7 +168,6 @@ __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, lon
     const cplx piv = sU[cq];
     const bool singular = piv.x == 0.0 && piv.y == 0.0;
     if (singular && tid == 0 && info[s] == 0) info[s] = r0 + 1;
-    if (nopiv && tid == 0 && !(fabs(piv.x) + fabs(piv.y) >= nopiv_rel * colmax) && info[s] == 0) info[s] = -(r0 + 1);
     const cplx rinv = singular ? make_double2(0.0, 0.0) : crecip(piv);
     cplx u[PW];
 #pragma unroll
@@ -340,6 +334,7 @@ struct TileGrid {
   cplx* pout; long long pout_ld, pout_stride; int pcol_tx;
   int tri;                                      // 1: only tiles with tx <= ty (square region, symmetric update)
   const int* tri_map; int tri_full;             // (ty << 16 | tx) of the first tri_full tiles of that order (the full bands)
+  unsigned long long per_sys_magic;             // ceil(2^40 / per_sys): t / per_sys = (t * magic) >> 40 for t < 2^25 (scalar multiply, no VALU division)
 };
 
 // the triangular order: lower triangle incl. the diagonal tiles in bands of 8 tile rows; band b (tile rows 8b .. 8b+hb-1) holds
@@ -366,8 +361,9 @@ __global__ void k_tri_map(int* map, int n) {
 }
 
 __device__ inline void tile_decode(const TileGrid& tg, int t, int& s, int& ty, int& tx) {
-  s = t / tg.per_sys;
+  s = (int)(((unsigned long long)(unsigned)t * tg.per_sys_magic) >> 40);
   int r = t - s * tg.per_sys;
+  if (r >= tg.per_sys) { r -= tg.per_sys; ++s; }      // (never taken for t < 2^25; kept as a guard)
   if (tg.tri) {
     if (r < tg.tri_full) { const int v = tg.tri_map[r]; ty = v >> 16; tx = v & 0xffff; }
     else tri_decode_band(r, tg.full_bands, tg.ty_n - 8 * tg.full_bands, ty, tx);      // the partial last band
@@ -936,6 +932,8 @@ static void launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, l
   tg.ty_n = (rrows + BM3 - 1) / BM3; tg.tx_n = (rcols + BN3 - 1) / BN3;
   tg.per_sys = tri ? tg.ty_n * (tg.ty_n + 1) / 2 : tg.ty_n * tg.tx_n; tg.full_bands = tg.ty_n / 8; tg.ntiles = tg.per_sys * nb;
   tg.tri_map = tri_map; tg.tri_full = 32 * tg.full_bands * tg.full_bands + 4 * tg.full_bands;
+  tg.per_sys_magic = ((1ULL << 40) + (unsigned long long)tg.per_sys - 1) / (unsigned long long)tg.per_sys;
+  if (tg.ntiles >= (1 << 25)) { set_error("biem_lu: more than 2^25 tiles in one update launch"); return; }   // unreachable: 2^25 tiles are 2 TB of matrix
   tg.row_begin = row_begin; tg.row_end = row_end; tg.col_begin = col_begin; tg.col_end = col_end; tg.brow = brow;
   const int cap = 512;                         // persistent grid: 2 workgroups per CU
   int want = (tg.ntiles + 7) / 8 * 8;          // one workgroup per tile up to the cap, multiple of 8
@@ -1252,11 +1250,11 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     // strips in pairs: after the first strip only the second strip's 8 columns are updated (rank 8); the columns right of
     // the pair get both strips' updates as ONE rank-16 pass (336 instead of 504 column passes per panel through HBM)
     for (int c0 = 0; c0 < NB; c0 += 2 * PW) {
-      hipLaunchKernelGGL(k_panel_strip, dim3(nb), dim3(1024), strip_lds, st, Pj, ldp, p_stride, n_pad, j, c0, 0, d_ipiv, d_info, nopiv);
+      hipLaunchKernelGGL(k_panel_strip, dim3(nb), dim3(1024), strip_lds, st, Pj, ldp, p_stride, n_pad, j, c0, 0, d_ipiv, d_info);
       int below = n_pad - (j + c0 + PW);
       if (below > 0)
         hipLaunchKernelGGL(k_panel_update<PW>, dim3((below + 255) / 256, nb), dim3(256), 0, st, Pj, ldp, p_stride, n_pad, j, c0, PW);
-      hipLaunchKernelGGL(k_panel_strip, dim3(nb), dim3(1024), strip_lds, st, Pj, ldp, p_stride, n_pad, j, c0 + PW, 1, d_ipiv, d_info, nopiv);
+      hipLaunchKernelGGL(k_panel_strip, dim3(nb), dim3(1024), strip_lds, st, Pj, ldp, p_stride, n_pad, j, c0 + PW, 1, d_ipiv, d_info);
       below = n_pad - (j + c0 + 2 * PW);
       const int ncols = NB - (c0 + 2 * PW);
       if (ncols > 0 && below > 0)

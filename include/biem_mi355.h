@@ -124,7 +124,7 @@ int biem_fill(const biem_plan* plan, int nb, int B, const double* d_k /*c128*/, 
  * biem_lu_factor_solve overwrites F with the solution (forward elimination rides in the trailing update, then a
  * blocked back substitution); A is overwritten by U and the un-permuted multipliers. */
 int biem_lu_npad(int N);
-size_t biem_lu_workspace_bytes(int nb, int n_pad, int nrhs);
+size_t biem_lu_workspace_bytes(int nb, int n_pad, int nrhs);   /* panels of a group + 64 x 64 block per system + tile map of the symmetric path */
 int biem_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride,
                          int* d_ipiv /*[nb][n_pad]*/, int* d_info /*[nb]*/, void* d_work, size_t work_bytes, void* stream);
 
