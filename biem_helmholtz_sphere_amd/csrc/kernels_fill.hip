@@ -395,43 +395,45 @@ __device__ inline cplx sym_r(const cplx* __restrict__ tball, int n_end, int n) {
 __global__ void __launch_bounds__(256) k_symmetrize(int H, int U, int n_end, int B, int nrhs, int n_pad, const int* __restrict__ units,
                                                      const int* __restrict__ deg, const cplx* __restrict__ tab, cplx* __restrict__ A,
                                                      long long lda, long long sys_stride) {
-  const int s = blockIdx.z, ru = blockIdx.y;                    // row unit over all balls
+  const int s = blockIdx.z;
   const int cu = blockIdx.x * 256 + threadIdx.x;                // column unit over all balls, then the right-hand sides
   if (cu >= B * U + nrhs) return;
-  const int br = ru / U, ur = ru - br * U;
-  const int rh = units[2 * ur], rp = units[2 * ur + 1];
-  const cplx* ts = tab + (size_t)s * B * 3 * n_end;
-  const cplx rr = sym_r(ts + (size_t)br * 3 * n_end, n_end, deg[rh]);
-  cplx* As = A + (size_t)s * sys_stride;
-  cplx* row_h = As + (size_t)(br * H + rh) * lda;
-  cplx* row_p = As + (size_t)(br * H + rp) * lda;
-  const double q2 = 0.70710678118654752440;
-  int ch, cp; cplx scale;
-  if (cu < B * U) {
-    const int bc = cu / U, uc = cu - bc * U;
-    ch = bc * H + units[2 * uc]; cp = bc * H + units[2 * uc + 1];
-    scale = cmul(rr, zsqrt(cmul(ts[(size_t)bc * 3 * n_end + deg[units[2 * uc]]], ts[(size_t)bc * 3 * n_end + n_end + deg[units[2 * uc]]])));   // r_row / r_col
-  } else { ch = cp = n_pad + (cu - B * U); scale = rr; }
-  // the L D L^T factorisation reads only the lower triangle and the diagonal 64 x 64 blocks: blocks wholly right of their
-  // rows' diagonal blocks are neither transformed nor written (their memory keeps the untransformed M; never read)
-  if (cu < B * U && (ch < cp ? ch : cp) >= ((br * H + (rh > rp ? rh : rp)) / 64 + 1) * 64) return;
-  cplx x00 = row_h[ch], x01 = row_h[cp], x10 = x00, x11 = x01;
-  if (rp != rh) { x10 = row_p[ch]; x11 = row_p[cp]; }
-  if (rp != rh) {   // rows: (h + p)/sqrt2, i (h - p)/sqrt2
-    cplx a0 = make_double2((x00.x + x10.x) * q2, (x00.y + x10.y) * q2), a1 = make_double2((x01.x + x11.x) * q2, (x01.y + x11.y) * q2);
-    cplx d0 = make_double2((x00.x - x10.x) * q2, (x00.y - x10.y) * q2), d1 = make_double2((x01.x - x11.x) * q2, (x01.y - x11.y) * q2);
-    x00 = a0; x01 = a1; x10 = make_double2(-d0.y, d0.x); x11 = make_double2(-d1.y, d1.x);
-  }
-  if (cp != ch) {   // columns: (h + p)/sqrt2, i (p - h)/sqrt2
-    cplx a0 = make_double2((x00.x + x01.x) * q2, (x00.y + x01.y) * q2), d0 = make_double2((x01.x - x00.x) * q2, (x01.y - x00.y) * q2);
-    cplx a1 = make_double2((x10.x + x11.x) * q2, (x10.y + x11.y) * q2), d1 = make_double2((x11.x - x10.x) * q2, (x11.y - x10.y) * q2);
-    x00 = a0; x01 = make_double2(-d0.y, d0.x); x10 = a1; x11 = make_double2(-d1.y, d1.x);
-  }
-  row_h[ch] = cmul(x00, scale);
-  if (cp != ch) row_h[cp] = cmul(x01, scale);
-  if (rp != rh) {
-    row_p[ch] = cmul(x10, scale);
-    if (cp != ch) row_p[cp] = cmul(x11, scale);
+  for (int ru = blockIdx.y; ru < B * U; ru += gridDim.y) {      // row unit over all balls (grid.y is capped at 65535)
+    const int br = ru / U, ur = ru - br * U;
+    const int rh = units[2 * ur], rp = units[2 * ur + 1];
+    const cplx* ts = tab + (size_t)s * B * 3 * n_end;
+    const cplx rr = sym_r(ts + (size_t)br * 3 * n_end, n_end, deg[rh]);
+    cplx* As = A + (size_t)s * sys_stride;
+    cplx* row_h = As + (size_t)(br * H + rh) * lda;
+    cplx* row_p = As + (size_t)(br * H + rp) * lda;
+    const double q2 = 0.70710678118654752440;
+    int ch, cp; cplx scale;
+    if (cu < B * U) {
+      const int bc = cu / U, uc = cu - bc * U;
+      ch = bc * H + units[2 * uc]; cp = bc * H + units[2 * uc + 1];
+      scale = cmul(rr, zsqrt(cmul(ts[(size_t)bc * 3 * n_end + deg[units[2 * uc]]], ts[(size_t)bc * 3 * n_end + n_end + deg[units[2 * uc]]])));   // r_row / r_col
+    } else { ch = cp = n_pad + (cu - B * U); scale = rr; }
+    // the L D L^T factorisation reads only the lower triangle and the diagonal 64 x 64 blocks: blocks wholly right of their
+    // rows' diagonal blocks are neither transformed nor written (their memory keeps the untransformed M; never read)
+    if (cu < B * U && (ch < cp ? ch : cp) >= ((br * H + (rh > rp ? rh : rp)) / 64 + 1) * 64) continue;
+    cplx x00 = row_h[ch], x01 = row_h[cp], x10 = x00, x11 = x01;
+    if (rp != rh) { x10 = row_p[ch]; x11 = row_p[cp]; }
+    if (rp != rh) {   // rows: (h + p)/sqrt2, i (h - p)/sqrt2
+      cplx a0 = make_double2((x00.x + x10.x) * q2, (x00.y + x10.y) * q2), a1 = make_double2((x01.x + x11.x) * q2, (x01.y + x11.y) * q2);
+      cplx d0 = make_double2((x00.x - x10.x) * q2, (x00.y - x10.y) * q2), d1 = make_double2((x01.x - x11.x) * q2, (x01.y - x11.y) * q2);
+      x00 = a0; x01 = a1; x10 = make_double2(-d0.y, d0.x); x11 = make_double2(-d1.y, d1.x);
+    }
+    if (cp != ch) {   // columns: (h + p)/sqrt2, i (p - h)/sqrt2
+      cplx a0 = make_double2((x00.x + x01.x) * q2, (x00.y + x01.y) * q2), d0 = make_double2((x01.x - x00.x) * q2, (x01.y - x00.y) * q2);
+      cplx a1 = make_double2((x10.x + x11.x) * q2, (x10.y + x11.y) * q2), d1 = make_double2((x11.x - x10.x) * q2, (x11.y - x10.y) * q2);
+      x00 = a0; x01 = make_double2(-d0.y, d0.x); x10 = a1; x11 = make_double2(-d1.y, d1.x);
+    }
+    row_h[ch] = cmul(x00, scale);
+    if (cp != ch) row_h[cp] = cmul(x01, scale);
+    if (rp != rh) {
+      row_p[ch] = cmul(x10, scale);
+      if (cp != ch) row_p[cp] = cmul(x11, scale);
+    }
   }
 }
 
@@ -460,10 +462,10 @@ int launch_symmetrize(const biem_plan* p, int nb, int B, int nrhs, int n_pad, co
                       long long sys_stride, bool inverse_on_solution, hipStream_t st) {
   const int U = (int)(p->units.size() / 2);
   if (nb <= 0 || B <= 0) return BIEM_OK;
-  if (nb > 65535 || B * U > 65535) { set_error("biem symmetric path: nb and n_balls * units must be <= 65535"); return BIEM_ERR_ARG; }
+  if (nb > 65535) { set_error("biem symmetric path: at most 65535 systems per call"); return BIEM_ERR_ARG; }
   ProfScope ps(PK_SWAP, st, 0.0);   // class 4: row interchanges in the LU, this transform in the symmetric path
   if (!inverse_on_solution)
-    hipLaunchKernelGGL(k_symmetrize, dim3((B * U + nrhs + 255) / 256, B * U, nb), dim3(256), 0, st, p->H, U, p->n_end, B, nrhs, n_pad,
+    hipLaunchKernelGGL(k_symmetrize, dim3((B * U + nrhs + 255) / 256, B * U < 65535 ? B * U : 65535, nb), dim3(256), 0, st, p->H, U, p->n_end, B, nrhs, n_pad,
                        p->d_units, p->d_deg, (const cplx*)d_tab, (cplx*)d_A, lda, sys_stride);
   else
     hipLaunchKernelGGL(k_unsymmetrize, dim3((B * U * nrhs + 255) / 256, nb), dim3(256), 0, st, p->H, U, p->n_end, B, nrhs, n_pad,
