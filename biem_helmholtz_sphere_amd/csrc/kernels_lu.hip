@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) k_panel_store(cplx* __restrict__ A, long 
 // ---------------------------------------------------------------------------------------------
 constexpr int PW = 8;
 
-constexpr double NOPIV_REL = 0.1;        // symmetric path: smallest accepted |diagonal| / |entry below it| (multipliers <= 10)
+constexpr double NOPIV_REL = 0.5;        // symmetric path: smallest accepted |diagonal| / |entry below it|: every multiplier <= 2 (partial pivoting: <= 1)
 constexpr int STRIP_CACHE_ROWS = 1024;   // rows of the strip kept in LDS (one per thread): 1024 x 8 x 16 B = 128 KiB
 
 __global__ void __launch_bounds__(1024) k_panel_strip(cplx* __restrict__ Pw, long long ldp, long long p_stride, int n_pad, int j, int c0,
