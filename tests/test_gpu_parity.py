@@ -647,3 +647,27 @@ def test_ldlt_near_a_resonance_and_forced_fallback(amd, monkeypatch):
         u = calc.uscat(_dev(x.T.copy())).cpu().numpy()
         for i in range(2):
             assert np.abs(u[:, i] - uo[i]).max() / np.abs(uo[i]).max() < 1e-10
+
+
+@pytest.mark.gpu
+def test_ldlt_natural_fallback_close_spheres(amd, monkeypatch):
+    """Two unit spheres 0.2 apart: at k = 10 the coupling is strong enough that some diagonal pivot is rejected (a multiplier
+    above 2) and that system - only that one - goes to the pivoted LU (tools/ldlt_stress.py surveys gaps and wavenumbers);
+    both routes agree with the LU-only path to rounding."""
+    from biem_helmholtz_sphere_amd import _biem as impl
+
+    c = amd.create_from_branching_types("ba")
+    cen, rad = np.array([[0.0, 1.1, 0.0], [0.0, -1.1, 0.0]]), np.array([1.0, 1.0])
+    ks = np.array([0.5, 10.0])
+    dirs = np.zeros((3, 2)); dirs[0] = 1.0
+    x = np.array([[6.0, 3.0, 0.1], [-5.0, 2.0, 1.0], [0.2, 7.0, -1.0]]).T
+    out = {}
+    for solver in ("ldlt", "lu"):
+        monkeypatch.setenv("BIEM_SOLVER", solver)
+        uin, ugr = amd.plane_wave(k=_dev(ks), direction=_dev(dirs))
+        calc = amd.biem(c, centers=_dev(cen)[None], radii=_dev(rad)[None], k=_dev(ks), eta=_dev(np.ones(2)), n_end=14, alpha=1.0, beta=0.3,
+                        uin=uin, uin_grad=ugr)
+        out[solver] = calc.uscat(_dev(x.copy())).cpu().numpy()
+        if solver == "ldlt":
+            assert impl._last_solve_stats == {"ldlt_systems": 2, "lu_systems": 1}
+    assert np.max(np.abs(out["ldlt"] - out["lu"]) / np.abs(out["lu"])) < 1e-12
