@@ -117,3 +117,23 @@ def test_cfg3_full_size_properties(amd):
     x = _probes(3, 10.5)
     u = calc.uscat(_dev(x.T)).cpu().numpy()
     assert np.isfinite(u).all()
+
+
+def test_beyond_the_configs_n12544_vs_oracle(amd):
+    """N = 12544 (16 balls, n_end 28: twice the headline N, 196 tile rows, 49 four-panel groups) against the oracle at 8 probe
+    points; the oracle's dense solve takes ~30 s on the GPU box's host cores."""
+    n_end = 28
+    ax = np.arange(-2, 2) * 4.0 + 2.0
+    x0, x1 = np.meshgrid(ax, ax, indexing="ij")
+    cen = np.stack([x0.ravel(), x1.ravel(), np.zeros(16)], -1)
+    ks = np.array([3.0, 7.5])
+    dirs = np.zeros((3, 2)); dirs[0] = 1
+    uin, _ = amd.plane_wave(k=_dev(ks), direction=_dev(dirs))
+    c = amd.create_from_branching_types("ba")
+    calc = amd.biem(c, centers=_dev(cen)[None], radii=_dev(np.ones(16))[None], k=_dev(ks), n_end=n_end, uin=uin)
+    ang = 2 * np.pi * np.arange(7) / 7
+    pts = np.concatenate([np.zeros((1, 3)), np.stack([10.5 * np.cos(ang), 10.5 * np.sin(ang), np.zeros(7)], -1)])
+    ug = calc.uscat(_dev(pts.T.copy())).cpu().numpy()
+    uo, _ = O.plane_wave(float(ks[1]), [1.0, 0, 0])
+    ref = O.uscat(O.solve_biem("ba", centers=cen, radii=np.ones(16), k=float(ks[1]), n_end=n_end, uin=uo), pts)
+    assert np.max(np.abs(ug[:, 1] - ref) / np.abs(ref)) < 1e-10
