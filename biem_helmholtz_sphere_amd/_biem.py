@@ -590,6 +590,11 @@ def biem(
     ``translational_coefficients_method`` is accepted for signature compatibility; this build always uses the
     exact closed form of SURVEY A.5 (the reference's "triplet" implementation is itself inexact).
     ``chunk`` (extension) bounds how many system matrices are resident at once (0 = choose).
+
+    Solver: the reference passes every system to a general dense solve (``_biem.py:797``).  Here the system is first brought
+    to its complex-symmetric form (real harmonics, symmetric scaling) and factored as L D L^T without interchanges - half the
+    flops; a system in which a multiplier would exceed 2 is solved by the pivoted LU instead (``BIEM_SOLVER=lu`` in the
+    environment: pivoted LU for all).  Both give the reference's ``density`` to rounding.
     """
     if translational_coefficients_method not in (None, "gumerov", "plane_wave", "triplet"):
         raise ValueError(f"Invalid translational_coefficients_method: {translational_coefficients_method}")
