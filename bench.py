@@ -1,19 +1,26 @@
 #!/usr/bin/env python
-"""bench.py -- BIEM systems solved per second on the BASELINE.json headline configuration.
+"""bench.py -- BIEM systems solved per second on the BASELINE.json configurations (default: configs[2], the headline).
 
-Workload (BASELINE.json configs[2], the one the metric is quoted on; it fits one GPU):
-    d=3 ('ba'), n_balls=16 on the 4x4 grid {-6,-2,2,6}^2 x {0} (reference cli.py:170-185 `_center(2,3)`), radius 1,
-    n_end=20 (N = 6400 unknowns per system), sound-soft, eta=1, plane wave along +x0 with the system's own k,
-    batch of wavenumbers k in [0.5, 8].
-One *step* = one pass of the whole hot path (boundary samples -> RHS projection -> fill -> symmetrise -> L D L^T (pivoted LU
-for systems whose diagonal pivots are rejected; BIEM_SOLVER=lu: LU for all) -> density) over this
-rank's shard of the batch through the public `biem()` API; inputs are resident in HBM when the clock starts, the
-densities are resident in HBM when it stops.  Weak scaling: every GPU owns `--systems-per-gpu` systems (default 256 =
-the whole 256-wavenumber batch of the config, which fits one MI355X: 256 x 656 MB of matrices); the k's of the whole job
-are linspace(0.5, 8, 256*N), rank r takes the r-th contiguous block.  No collective sits in the data path (independent systems); RCCL is
-used only for the barrier / max-reduce of the timing.
+One *step* = one pass of the whole hot path (boundary samples -> RHS projection -> fill -> complex-symmetric L D L^T, or the
+pivoted LU for systems it rejects / BIEM_SOLVER=lu -> density) over this rank's systems through the public `biem()` API;
+inputs are resident in HBM when the clock starts, the densities are resident in HBM when it stops.
 
-Prints ONE JSON line on rank 0 (fields per the driver contract, plus `roofline` and `cpu_baseline`).
+Workloads (SURVEY 8(d) inputs; radii 1, plane wave along +x0 with each system's own k, eta = 1 unless stated):
+  --config 1  d=3 'ba', 2 balls at (0, +-2, 0), n_end 6 (N = 72), k = 1            [the config is ONE system: the batch is S copies]
+  --config 2  d=3, 4 balls (2 x 2 grid, pitch 4), n_end 12 (N = 576), k = 1         [one system: S copies]
+  --config 3  d=3, 16 balls (4 x 4 grid, pitch 4), n_end 20 (N = 6400), 256 wavenumbers linspace(0.5, 8)      (default)
+  --config 4  d=2 'a', 32 balls (4 x 8 grid), n_end 64 (N = 4064), Robin alpha = beta = 1, k = 1             [one system: S copies]
+  --config 5  d=4 'bba', 8 balls (2 x 4 grid), n_end 10 (N = 3080), 512 pairs = 32 k in linspace(0.5, 4) x 16 eta in linspace(0.25, 4)
+S = --systems-per-gpu (defaults 4096 / 512 / 256 / 64 / 512).  For the one-system configs the line also carries
+`single_system_ms` (one system per call, what the config literally describes; launch-latency bound).
+
+Multi-GPU: one process per GPU.  Under torchrun (WORLD_SIZE set) the ranks are used as given; `python bench.py --gpus N` alone
+starts N child processes itself (the parent never touches a GPU).  --scaling weak (default): every GPU owns S systems, the k's
+of the whole job are one linspace of S*N values; --scaling strong: the config's S systems are split S/N per GPU.  No collective
+sits in the timed data path (independent systems); RCCL carries the barrier / max-reduce of the timing and,
+outside the timed region, one all-gather of the densities (`marshalling_ms`).
+
+Prints ONE JSON line on rank 0 (fields per the driver contract, plus `roofline`, `fill` and `cpu_baseline`).
 """
 from __future__ import annotations
 
@@ -21,86 +28,212 @@ import argparse
 import ctypes as C
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X FP64 matrix, vendor spec (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz)
+FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X FP64 matrix, vendor spec (256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz); probe: profiles/r01_mfma_f64_*
+HBM_PEAK_GBS = 8000.0
 CLASSES = ["tables", "fill", "rhs", "panel", "swap", "trsm", "gemm", "back", "gemm_small"]
+DEFAULT_SYSTEMS = {1: 4096, 2: 512, 3: 256, 4: 64, 5: 512}
 
 
-def workload(n_sys_total: int, rank: int, world: int, per_gpu: int, dev):
-    half, d = 2, 3
-    ax = np.arange(-half, half) * 4.0 + 2.0
-    x0, x1 = np.meshgrid(ax, ax, indexing="ij")
-    centers = np.stack([x0.ravel(), x1.ravel(), np.zeros(x0.size)], axis=-1)          # [16, 3]
-    ks_all = np.linspace(0.5, 8.0, n_sys_total)
-    ks = ks_all[rank * per_gpu:(rank + 1) * per_gpu]
-    t = lambda a: torch.as_tensor(np.array(a), dtype=torch.float64, device=dev)
-    dirs = np.zeros((d, len(ks)))
-    dirs[0] = 1.0
-    return dict(centers=t(centers)[None], radii=t(np.ones(len(centers)))[None], k=t(ks), eta=t(np.ones(len(ks))),
-                direction=t(dirs), ks=ks, centers_np=centers)
+# ------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------
+def _grid(ax0, ax1, d):
+    x0, x1 = np.meshgrid(ax0, ax1, indexing="ij")
+    cen = np.zeros((x0.size, d))
+    cen[:, 0], cen[:, 1] = x0.ravel(), x1.ravel()
+    return cen
 
 
-def cpu_baseline(n_end: int, centers: np.ndarray, ks):
-    """The oracle (CPU restatement of the reference path: materialise the matrix, numpy.linalg.solve) timed on a few
-    systems of the same workload on this host's cores, one after the other as the reference would run them.
-    Returns the systems' results (for the accuracy check), the total time and the BLAS thread count."""
-    from oracle import biem_oracle as O   # checker / baseline only
+def workload(cfg: int, n_total: int, lo: int, hi: int):
+    """Systems lo..hi-1 of a job of n_total systems of configuration `cfg` (NumPy; the caller moves them to the device)."""
+    if cfg == 1:
+        tree, n_end, cen = "ba", 6, np.array([[0.0, 2.0, 0.0], [0.0, -2.0, 0.0]])
+        ks, etas, ab = np.ones(n_total), np.ones(n_total), (1.0, 0.0)
+        desc = f"cfg1: d=3 'ba', 2 balls at (0,+-2,0), n_end=6, N=72, k=1, sound-soft; {n_total} copies of the one system of the config"
+    elif cfg == 2:
+        ax = np.array([-2.0, 2.0])
+        tree, n_end, cen = "ba", 12, _grid(ax, ax, 3)
+        ks, etas, ab = np.ones(n_total), np.ones(n_total), (1.0, 0.0)
+        desc = f"cfg2: d=3 'ba', 4 balls (2x2 grid, pitch 4), n_end=12, N=576, k=1, sound-soft; {n_total} copies of the one system of the config"
+    elif cfg == 3:
+        ax = np.arange(-2, 2) * 4.0 + 2.0
+        tree, n_end, cen = "ba", 20, _grid(ax, ax, 3)
+        ks, etas, ab = np.linspace(0.5, 8.0, n_total), np.ones(n_total), (1.0, 0.0)
+        desc = f"cfg3: d=3 'ba', n_balls=16 (4x4 grid, pitch 4), n_end=20, N=6400, sound-soft, {n_total} wavenumbers linspace(0.5, 8, {n_total})"
+    elif cfg == 4:
+        tree, n_end, cen = "a", 64, _grid(np.arange(4) * 4.0 - 6.0, np.arange(8) * 4.0 - 14.0, 2)
+        ks, etas, ab = np.ones(n_total), np.ones(n_total), (1.0, 1.0)
+        desc = f"cfg4: d=2 'a', 32 balls (4x8 grid, pitch 4), n_end=64, N=4064, Robin alpha=beta=1, k=1; {n_total} copies of the one system of the config"
+    elif cfg == 5:
+        tree, n_end, cen = "bba", 10, _grid(np.arange(2) * 4.0 - 2.0, np.arange(4) * 4.0 - 6.0, 4)
+        nk = max(1, n_total // 16)
+        kk, ee = np.meshgrid(np.linspace(0.5, 4.0, nk), np.linspace(0.25, 4.0, 16), indexing="ij")
+        ks, etas, ab = kk.ravel()[:n_total], ee.ravel()[:n_total], (1.0, 0.0)
+        if len(ks) < n_total:
+            raise SystemExit("cfg5: the number of systems must be a multiple of 16 (k's x 16 eta's)")
+        desc = f"cfg5: d=4 'bba', 8 balls (2x4 grid, pitch 4), n_end=10, N=3080, sound-soft, {n_total} (k, eta) pairs = {nk} k in linspace(0.5,4) x 16 eta in linspace(0.25,4)"
+    else:
+        raise SystemExit(f"unknown --config {cfg}")
+    return dict(tree=tree, n_end=n_end, centers=cen, ks=ks[lo:hi], etas=etas[lo:hi], alpha=ab[0], beta=ab[1], desc=desc,
+                d=cen.shape[1], B=len(cen))
 
-    O._terms3(n_end)                      # table build is amortised over a sweep: keep it out of the timing
-    results = []
-    t0 = time.perf_counter()
-    for k in ks:
-        uin, _ = O.plane_wave(float(k), [1.0, 0.0, 0.0])
-        res = O.solve_biem("ba", centers=centers, radii=np.ones(len(centers)), k=float(k), n_end=n_end, eta=1.0, uin=uin)
-        results.append(res)
-    dt = time.perf_counter() - t0
-    res = results
+
+def harm_count(tree: str, n_end: int) -> int:
+    return {"a": 2 * n_end - 1, "ba": n_end**2, "bba": n_end * (n_end + 1) * (2 * n_end + 1) // 6}[tree]
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (BASELINE.md section 3): the oracle = this repo's NumPy/LAPACK restatement of the reference's CPU path
+# ------------------------------------------------------------------------------------------------
+def _blas_threads():
     try:
         from threadpoolctl import threadpool_info
 
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        return max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
-        threads = os.cpu_count() or 1
-    return res, dt, threads
+        return os.cpu_count() or 1
 
 
-def main():
+def _oracle_systems(w, idx, reps):
+    """Per-system wall times (median over `reps` after one warm-up when reps > 1) of oracle fill + numpy.linalg.solve."""
+    from oracle import biem_oracle as O   # checker / baseline only
+
+    e0 = np.zeros(w["d"])
+    e0[0] = 1.0
+    results, times = [], []
+    for i in idx:
+        k, eta = float(w["ks"][i]), float(w["etas"][i])
+        uin, ugr = O.plane_wave(k, e0)
+
+        def one():
+            t0 = time.perf_counter()
+            r = O.solve_biem(w["tree"], centers=w["centers"], radii=np.ones(w["B"]), k=k, n_end=w["n_end"], eta=eta, alpha=w["alpha"],
+                             beta=w["beta"], uin=uin, uin_grad=ugr if w["beta"] != 0 else None)
+            return r, time.perf_counter() - t0
+
+        if reps > 1:
+            one()
+        ts = []
+        for _ in range(reps):
+            r, t = one()
+            ts.append(t)
+        results.append(r)
+        times.append(statistics.median(ts))
+    return results, times
+
+
+def cpu_baseline(w, n_sys: int, reps: int, one_thread: bool):
+    """Oracle timed on `n_sys` systems spread over the rank's batch (all BLAS threads), and on one system with one thread."""
+    from oracle import biem_oracle as O
+
+    if w["tree"] == "ba":
+        O._terms3(w["n_end"])             # table build is amortised over a sweep: keep it out of the timing
+    else:
+        _oracle_systems(w, [0], 1)        # warm the tree's table caches
+    nb = len(w["ks"])
+    idx = sorted(set(int(round(v)) for v in np.linspace(0, nb - 1, min(n_sys, nb))))
+    t_all0 = time.perf_counter()
+    res, times = _oracle_systems(w, idx, reps)
+    threads = _blas_threads()
+    out = {"value": 1.0 / statistics.median(times), "unit": "systems/s", "cores": int(threads), "os_cpu_count": os.cpu_count(),
+           "kind": "port",
+           "sample": f"{len(idx)} systems of the workload (batch indices {idx}), per system the median of {reps} run(s)"
+                     f"{' after one warm-up' if reps > 1 else ''} of oracle fill + numpy.linalg.solve; value = 1 / median over the systems "
+                     f"({', '.join(f'{t:.2f}' for t in times)} s); {time.perf_counter() - t_all0:.1f} s in all"}
+    if one_thread:
+        try:
+            from threadpoolctl import threadpool_limits
+
+            with threadpool_limits(limits=1):
+                t0 = time.perf_counter()
+                _, t1 = _oracle_systems(w, idx[:1], 1)
+            out["one_thread"] = {"value": 1.0 / t1[0], "unit": "systems/s", "cores": 1,
+                                 "sample": f"system {idx[0]} once with BLAS limited to 1 thread, {time.perf_counter() - t0:.1f} s"}
+        except Exception as e:  # noqa: BLE001
+            out["one_thread"] = {"value": None, "error": str(e)}
+    return res, idx, out
+
+
+# ------------------------------------------------------------------------------------------------
+def _spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks as child processes.  This parent never initialises a GPU
+    (device_count() does not, on this image) and does not exec over itself; it returns rank 0's exit code (first failure wins)."""
+    import socket
+
+    import torch
+
+    share = os.environ.get("BIEM_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < args.gpus and not share:
+        print(f"bench.py: --gpus {args.gpus} but only {have} HIP device(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--systems-per-gpu", type=int, default=256)
-    ap.add_argument("--n-end", type=int, default=20)
+    ap.add_argument("--config", type=int, default=3, choices=[1, 2, 3, 4, 5])
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--systems-per-gpu", type=int, default=0, help="0 = the config's batch (cfg3: 256, cfg5: 512; one-system configs: copies)")
     ap.add_argument("--chunk", type=int, default=0, help="resident matrices per pass (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-systems", type=int, default=4)
+    ap.add_argument("--cpu-baseline-reps", type=int, default=1, help="BASELINE.md section 3 asks for 5; the default keeps the run short")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return _spawn_ranks(args)
+
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     # one rank per GPU; BIEM_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box only) folds the ranks onto the visible devices
     share = os.environ.get("BIEM_BENCH_SHARE_GPU") == "1"
+    if not share and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} HIP device(s) visible")
     dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    # BIEM_BENCH_FORCE_DIST=1: build the process group at world size 1 too (exercises the RCCL barrier / max-reduce on a 1-GPU box)
+    # BIEM_BENCH_FORCE_DIST=1: build the process group at world size 1 too (exercises the RCCL barrier / max-reduce / gather on a 1-GPU box)
     if world > 1 or os.environ.get("BIEM_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if share:
             dist.init_process_group(backend="gloo")           # RCCL refuses two ranks on one device
         else:
@@ -108,17 +241,30 @@ def main():
 
     import biem_helmholtz_sphere_amd as amd
     from biem_helmholtz_sphere_amd import _biem as impl
+    from biem_helmholtz_sphere_amd import _dist as D
     from biem_helmholtz_sphere_amd import _lib as L
 
     lib = L.load()
-    per_gpu = args.systems_per_gpu
-    w = workload(per_gpu * world, rank, world, per_gpu, dev)
-    c = amd.create_from_branching_types("ba")
-    uin, _ = amd.plane_wave(k=w["k"], direction=w["direction"])
+    cfg = args.config
+    S = args.systems_per_gpu or DEFAULT_SYSTEMS[cfg]
+    if args.scaling == "weak":
+        n_total, (lo, hi) = S * world, (rank * S, (rank + 1) * S)
+    else:
+        n_total, (lo, hi) = S, D.shard_bounds(S, rank, world)
+    w = workload(cfg, n_total, lo, hi)
+    nloc = hi - lo
+    t = lambda a, dt=torch.float64: torch.as_tensor(np.array(a), device=dev).to(dt).contiguous()
+    c = amd.create_from_branching_types(w["tree"])
+    dirs = np.zeros((w["d"], nloc))
+    dirs[0] = 1.0
+    k_t, eta_t = t(w["ks"]), t(w["etas"])
+    uin, ugr = amd.plane_wave(k=k_t, direction=t(dirs))
+    kw = dict(centers=t(w["centers"])[None], radii=t(np.ones(w["B"]))[None], n_end=w["n_end"], alpha=w["alpha"], beta=w["beta"])
+    if w["beta"] != 0:
+        kw["uin_grad"] = ugr
 
     def step():
-        return amd.biem(c, centers=w["centers"], radii=w["radii"], k=w["k"], eta=w["eta"], n_end=args.n_end, uin=uin,
-                        chunk=args.chunk)
+        return amd.biem(c, k=k_t, eta=eta_t, uin=uin, chunk=args.chunk, **kw)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -140,54 +286,90 @@ def main():
     work = (C.c_double * 9)()
     launches = (C.c_longlong * 9)()
     L.check(lib.biem_profile_end(ms, work, launches))
+    marshalling_ms, rccl_ranks = None, None
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # output marshalling (outside the timed region): all-gather of the densities, as _dist.biem_sharded does
+        rccl_ranks = dist.get_world_size()
+        dens = calc.density if not share else calc.density.cpu()
+        D.gather_batch(dens, n_total if args.scaling == "strong" else S * world)          # warm-up (communicator set-up)
+        barrier()
+        tg = time.perf_counter()
+        full = D.gather_batch(dens, n_total if args.scaling == "strong" else S * world)
+        barrier()
+        marshalling_ms = (time.perf_counter() - tg) * 1e3
+        assert full.shape[0] == n_total
+        del full
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
-        return
+        return 0
 
-    n_sys = per_gpu * world * args.steps
-    value = n_sys / dt
+    systems_per_step = n_total
+    value = systems_per_step * args.steps / dt
     ms, work, launches = list(ms), list(work), list(launches)
-    gi = CLASSES.index("gemm")
-    gemm_tflops = work[gi] / (ms[gi] * 1e-3) / 1e12 if ms[gi] > 0 else None
-    fi = CLASSES.index("fill")
+    gi, fi = CLASSES.index("gemm"), CLASSES.index("fill")
+    alg_tflops = work[gi] / (ms[gi] * 1e-3) / 1e12 if ms[gi] > 0 else None     # 8 real flops per complex multiply-add
     fill_gbs = work[fi] / (ms[fi] * 1e-3) / 1e9 if ms[fi] > 0 else None
-    N = 16 * args.n_end ** 2
-    lu_flops = (8.0 / 3.0) * N ** 3
+    H = harm_count(w["tree"], w["n_end"])
+    N = w["B"] * H
+    solver = os.environ.get("BIEM_SOLVER", "ldlt")
 
-    # accuracy of this run's densities vs the CPU oracle at probe points (max rel-err, metric's second half)
-    cpu = None
-    relerr = None
-    if not args.no_cpu_baseline and world == 1:     # the CPU baseline and the accuracy check run at N = 1 only
-        cpu_ks = [w["ks"][0], w["ks"][-1]] if len(w["ks"]) > 1 else [w["ks"][0]]
-        res, cpu_dt, threads = cpu_baseline(args.n_end, w["centers_np"], cpu_ks)
-        ang = 2 * np.pi * np.arange(63) / 63
-        probes = np.concatenate([np.zeros((1, 3)), np.stack([10.5 * np.cos(ang), 10.5 * np.sin(ang), np.zeros(63)], -1)])
+    # the one-system configs: latency of a single system per call (what the config literally describes)
+    single_ms = None
+    if cfg in (1, 2, 4):
+        u1, g1 = amd.plane_wave(k=k_t[:1], direction=t(dirs[:, :1]))
+        kw1 = dict(kw)
+        if w["beta"] != 0:
+            kw1["uin_grad"] = g1
+        for _ in range(3):
+            amd.biem(c, k=k_t[:1], eta=eta_t[:1], uin=u1, **kw1)
+        torch.cuda.synchronize(dev)
+        ts = time.perf_counter()
+        for _ in range(10):
+            amd.biem(c, k=k_t[:1], eta=eta_t[:1], uin=u1, **kw1)
+        torch.cuda.synchronize(dev)
+        single_ms = (time.perf_counter() - ts) * 100.0
+
+    # accuracy of this run's densities vs the CPU oracle at probe points (the metric's second half) + the CPU baseline
+    cpu, relerr = None, None
+    if not args.no_cpu_baseline and world == 1:     # rank 0 at N = 1 only
         from oracle import biem_oracle as O
 
-        ug = calc.uscat(torch.as_tensor(probes.T.copy(), dtype=torch.float64, device=dev)).cpu().numpy()
+        res, idx, cpu = cpu_baseline(w, args.cpu_baseline_systems, args.cpu_baseline_reps, one_thread=True)
+        half = float(np.max(np.abs(w["centers"]))) + 1.0
+        ang = 2 * np.pi * np.arange(63) / 63
+        probes = np.zeros((64, w["d"]))
+        probes[1:, 0], probes[1:, 1] = 1.5 * half * np.cos(ang), 1.5 * half * np.sin(ang)
+        ug = calc.uscat(t(probes.T.copy())).cpu().numpy()
         relerr = 0.0
-        for r, col in zip(res, [0, -1]):
+        for r, i in zip(res, idx):
             uo = O.uscat(r, probes)
-            relerr = max(relerr, float(np.max(np.abs(ug[:, col] - uo) / np.abs(uo))))
-        cpu = {"value": len(cpu_ks) / cpu_dt, "unit": "systems/s", "cores": int(threads), "kind": "port",
-               "sample": f"{len(cpu_ks)} systems of the workload (k = " + ", ".join(f"{k:.4g}" for k in cpu_ks)
-                         + f"), oracle fill + numpy.linalg.solve one after the other, {cpu_dt:.1f} s"}
+            relerr = max(relerr, float(np.max(np.abs(ug[:, i] - uo) / np.abs(uo))))
 
-    # HBM traffic of the dominant kernel per launch: measured once with rocprofv3 PMC passes (cannot run inside bench.py);
-    # bytes per launch per system from the committed summary, scaled to this run's systems per launch
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
-    if os.path.exists(tpath) and args.n_end == 20:
-        with open(tpath) as f:
-            tj = json.load(f)
-            traffic = tj["bytes_per_launch_per_system" if os.environ.get("BIEM_SOLVER", "ldlt") == "ldlt" else "bytes_per_launch_per_system_lu"] * per_gpu
+    # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside bench.py; bytes per launch per system from
+    # the committed summary, scaled to this run's systems per launch
+    def profile_json(name):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            with open(p) as f:
+                return json.load(f)
+        return None
 
+    traffic, traffic_src = None, None
+    tj = profile_json("r02_gemm_traffic.json") or profile_json("r01_gemm_traffic.json")
+    if tj and cfg == 3:
+        key = "bytes_per_launch_per_system" if solver == "ldlt" else "bytes_per_launch_per_system_lu"
+        traffic = tj[key] * min(nloc, args.chunk or nloc)
+        traffic_src = (f"profiles/{'r02' if profile_json('r02_gemm_traffic.json') else 'r01'}_gemm_traffic.json: rocprofv3 --pmc passes at "
+                       f"{tj.get('systems_per_launch', 8)} systems per launch (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), scaled to {min(nloc, args.chunk or nloc)} systems per launch; not measured in this run")
+    fj = profile_json("r02_fill_traffic.json")
+    fill_traffic = fj["bytes_per_system"] * nloc if fj and cfg == 3 else None
+
+    issued = 0.75 * alg_tflops if alg_tflops else None     # 3M: 3 real products per complex multiply-add = 6 of the 8 flops
     out = {
         "metric": "BIEM systems solved/sec + max |u_scat| rel-err vs NumPy ref",
         "value": value,
@@ -197,35 +379,38 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "c128",
         "data": "synthetic",
-        "config": {"workload": f"cfg3: d=3 'ba', n_balls=16 (4x4 grid, pitch 4), n_end={args.n_end}, N={N}, sound-soft, "
-                               f"{per_gpu} wavenumbers per GPU from linspace(0.5, 8, {per_gpu * world})",
-                   "systems_per_gpu": per_gpu, "parallelism": f"batch-shard x{world}",
-                   "solver": os.environ.get("BIEM_SOLVER", "ldlt"), "solved_by": dict(impl._last_solve_stats)},
+        "config": {"workload": w["desc"], "config_id": cfg, "N": N, "systems_per_step": systems_per_step, "systems_per_gpu": nloc,
+                   "parallelism": f"batch-shard x{world}", "solver": solver, "solved_by": dict(impl._last_solve_stats)},
         "max_rel_err_uscat": relerr,
         "roofline": {
-            "bound": "mfma", "kernel": "k_gemm3m_pipe<256> (zgemm3m K=256 trailing update of a four-panel group, v_mfma_f64_4x4x4_4b_f64; lower-triangle tiles in the L D L^T path)",
-            "achieved": gemm_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": (gemm_tflops / FP64_MFMA_PEAK_TFLOPS) if gemm_tflops else None,
-            # `achieved` counts the ALGORITHMIC 8 real flops per complex multiply-add; the 3M form issues 6 of them as MFMAs
-            # (3 real products instead of 4), so the matrix pipe itself runs at 3/4 of `achieved`:
-            "mfma_issued_tflops": 0.75 * gemm_tflops if gemm_tflops else None,
-            "mfma_issued_frac": (0.75 * gemm_tflops / FP64_MFMA_PEAK_TFLOPS) if gemm_tflops else None,
-            "traffic": traffic,
-            "avg_launch_ms": ms[gi] / launches[gi] if launches[gi] else None,
-            "lu_effective_tflops": lu_flops * per_gpu * args.steps / (sum(ms[3:9]) * 1e-3) / 1e12 if sum(ms[3:9]) > 0 else None,
+            "bound": "mfma",
+            "kernel": "k_gemm3m_pipe<256> (zgemm3m K=256 trailing update of a four-panel group, v_mfma_f64_4x4x4_4b_f64; lower-triangle tiles in the L D L^T path)",
+            # `achieved` = flops the matrix pipe EXECUTES: the 3M form does a complex multiply-add in 3 real products = 6 real flops
+            "achieved": issued, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": issued / FP64_MFMA_PEAK_TFLOPS if issued else None,
+            # the same launches priced at the textbook 8 real flops per complex multiply-add (what a 4M zgemm would execute)
+            "algorithmic_tflops_8flop": alg_tflops,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "avg_launch_ms": ms[gi] / launches[gi] if launches[gi] else None, "launches": launches[gi],
+            "share_of_step": ms[gi] / (dt * 1e3) if dt > 0 else None,
         },
-        "fill": {"bound": "hbm", "achieved": fill_gbs, "peak": 8000.0, "unit": "GB/s", "frac": fill_gbs / 8000.0 if fill_gbs else None},
+        "fill": {"bound": "hbm", "achieved": fill_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fill_gbs / HBM_PEAK_GBS if fill_gbs else None,
+                 "bytes_counted": "16 N^2 per system (BIEM_SOLVER=lu) or what the L D L^T path reads: lower triangle + diagonal 64-blocks",
+                 "traffic": fill_traffic, "traffic_source": "profiles/r02_fill_traffic.json (rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE), scaled" if fill_traffic else None},
         "stage_ms_per_step": {n: m / args.steps for n, m in zip(CLASSES, ms)},
+        "single_system_ms": single_ms,
+        "marshalling_ms": marshalling_ms, "rccl_ranks": rccl_ranks,
         "cpu_baseline": cpu,
     }
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -426,8 +426,33 @@ def _validate_biem_inputs(c, centers, radii, k, eta, alpha, beta) -> Tuple[int, 
     return tuple(batch)
 
 
+def _any(a: Any) -> bool:
+    return bool(a.any()) if isinstance(a, (torch.Tensor, np.ndarray)) else bool(np.any(a))
+
+
+def _warn_biem_inputs(k: Any, eta: Any) -> None:
+    """The two UserWarnings of reference :269-285 (texts verbatim, missing blanks included), on the caller's arrays
+    (NumPy or torch, any device): eta == 0 somewhere; Im k < 0 or eta Re k < 0 somewhere.  (The reference's own test of the
+    second one, :278-280, guards the Im k term with "eta is not castable to float64", which is never true once the complex-eta
+    check above it has passed, so there only eta Re k < 0 can fire; here the condition the message states is checked.)"""
+    if eta is not None and _any(eta == 0):
+        warnings.warn(
+            "The solution may be incorrect"
+            "if k is an eigenvalue for laplacian"
+            "on the interior region with"
+            "Neumann boundary condition.",
+            UserWarning,
+            stacklevel=4,
+        )
+    k_re, k_im = (k.real, k.imag) if _is_complex(k) else (k, None)
+    bad = (k_im is not None and _any(k_im < 0)) or _any((k_re if eta is None else eta * k_re) < 0)
+    if bad:
+        warnings.warn("The solution may be incorrectif not (Im k >= 0 and eta Re k >= 0).", UserWarning, stacklevel=4)
+
+
 def _check_biem_inputs(c, centers, radii, k, eta, alpha, beta):
     batch = _validate_biem_inputs(c, centers, radii, k, eta, alpha, beta)
+    _warn_biem_inputs(k, eta)
     origin, dev = _origin_of(centers, radii, k, eta, alpha, beta)
     f64 = torch.float64
     centers_t = _to_dev(centers, dev, f64)
@@ -443,17 +468,6 @@ def _check_biem_inputs(c, centers, radii, k, eta, alpha, beta):
     beta_t = _to_dev(beta, dev, torch.complex128)
     if beta_t.ndim == 0:
         beta_t = beta_t[(None,) * (k_t.ndim + 1)]
-    if bool(torch.any(eta_t == 0)):
-        warnings.warn(
-            "The solution may be incorrect"
-            "if k is an eigenvalue for laplacian"
-            "on the interior region with"
-            "Neumann boundary condition.",
-            UserWarning,
-            stacklevel=3,
-        )
-    if bool(torch.any(k_t.imag < 0)) or bool(torch.any(eta_t * k_t.real < 0)):
-        warnings.warn("The solution may be incorrectif not (Im k >= 0 and eta Re k >= 0).", UserWarning, stacklevel=3)
     return origin, dev, batch, centers_t, radii_t, k_t, eta_t, alpha_t, beta_t
 
 

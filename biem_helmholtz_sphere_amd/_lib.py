@@ -18,9 +18,10 @@ USCAT_FAR_FIELD, USCAT_PER_BALL, USCAT_KIND_INNER, USCAT_POINTS_BATCHED = 1, 2, 
 
 _vp, _i, _ll, _sz, _dp, _ip = C.c_void_p, C.c_int, C.c_longlong, C.c_size_t, C.c_void_p, C.c_void_p
 
-# name -> (restype, argtypes): must list every symbol of include/biem_mi355.h (tests/test_abi.py checks it)
+# name -> (restype, argtypes): must list every symbol of include/biem_mi355.h (tests/test_host_logic.py::test_library_exports_every_declared_symbol checks it)
 SIGNATURES = {
     "biem_version": (_i, []),
+    "biem_build_id": (C.c_char_p, []),
     "biem_last_error": (C.c_char_p, []),
     "biem_device_count": (_i, [C.POINTER(_i)]),
     "biem_plan_create_host": (_i, [_i, _i, C.POINTER(_vp)]),
@@ -42,6 +43,9 @@ SIGNATURES = {
     "biem_lu_npad": (_i, [_i]),
     "biem_lu_workspace_bytes": (_sz, [_i, _i, _i]),
     "biem_lu_factor_solve": (_i, [_i, _i, _i, _dp, _ll, _ll, _ip, _ip, _vp, _sz, _vp]),
+    "biem_lu_factor": (_i, [_i, _i, _dp, _ll, _ll, _ip, _ip, _vp, _sz, _vp]),
+    "biem_ldlt_factor": (_i, [_i, _i, _dp, _ll, _ll, _ip, _ip, _vp, _sz, _vp]),
+    "biem_lu_solve": (_i, [_i, _i, _i, _dp, _ll, _ll, _ip, _dp, _ll, _ll, _vp]),
     "biem_density": (_i, [_vp, _i, _i, _i, _dp, _ll, _ll, _ll, _dp, _dp, _vp]),
     "biem_uscat_workspace_bytes": (_sz, [_vp, _i, _i]),
     "biem_uscat": (_i, [_vp, _i, _i, _i, _dp, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _vp, _sz, _vp]),
@@ -63,30 +67,39 @@ class BiemLibraryError(RuntimeError):
 
 
 def load() -> C.CDLL:
-    """Load the HIP library; raises loudly if it has not been built (no fallback path exists)."""
+    """Load the HIP library; raises loudly if it is missing and cannot be built (no fallback path exists).
+
+    The existence / staleness test and a rebuild happen under a file lock (one process per GPU: several ranks get here at
+    once), the build writes a temporary file and renames it, so no rank ever maps a half-written library.  A library whose
+    stored source hash differs from the checkout's (`_build.is_stale`) is rebuilt when hipcc is present; without hipcc a
+    missing library is an error and a stale one a warning.
+    """
     global _lib
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH):
-            # not a fallback: the same HIP library, compiled now if the toolchain is present
-            try:
-                import fcntl
+        import fcntl
 
-                from . import _build
+        from . import _build
 
-                # several ranks may get here at once (one process per GPU): one builds, the others wait and re-check
-                with open(LIB_PATH + ".lock", "w") as lk:
-                    fcntl.flock(lk, fcntl.LOCK_EX)
-                    if not os.path.exists(LIB_PATH):
-                        _build.build(force=True)
-            except Exception as e:  # noqa: BLE001
-                raise BiemLibraryError(
-                    f"{LIB_PATH} is missing and could not be built ({e}). Build it with "
-                    "`python -m biem_helmholtz_sphere_amd._build` (hipcc --offload-arch=gfx950). "
-                    "This package has no CPU fallback."
-                ) from e
-        lib = C.CDLL(LIB_PATH)
+        with open(LIB_PATH + ".lock", "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            missing = not os.path.exists(LIB_PATH)
+            if missing or _build.is_stale():
+                try:
+                    _build.build(force=True)       # not a fallback: the same HIP library, compiled now
+                except Exception as e:  # noqa: BLE001
+                    if missing:
+                        raise BiemLibraryError(
+                            f"{LIB_PATH} is missing and could not be built ({e}). Build it with "
+                            "`python -m biem_helmholtz_sphere_amd._build` (hipcc --offload-arch=gfx950). "
+                            "This package has no CPU fallback."
+                        ) from e
+                    import warnings
+
+                    warnings.warn(f"{LIB_PATH} was built from other sources than this checkout's csrc/ (hash "
+                                  f"{_build.built_hash()} vs {_build.source_hash()}) and could not be rebuilt: {e}", RuntimeWarning)
+            lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = res

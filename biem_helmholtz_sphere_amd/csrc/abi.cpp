@@ -21,7 +21,14 @@ hipEvent_t Profiler::get() {
 
 extern "C" {
 
-int biem_version(void) { return 100; }   // 0.1.0
+int biem_version(void) { return 200; }   // 0.2.0
+
+// hash of the sources this library was built from (set by _build.py; the loader compares it with the checkout's)
+#ifndef BIEM_SRC_HASH
+#define BIEM_SRC_HASH "unknown"
+#endif
+extern const char biem_src_hash_marker[] = "BIEM_SRC_HASH=" BIEM_SRC_HASH ";";
+const char* biem_build_id(void) { return BIEM_SRC_HASH; }
 
 const char* biem_last_error(void) { return last_error(); }
 
@@ -159,6 +166,24 @@ int biem_ldlt_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
   const char* e = getenv("BIEM_LU_DISCARD_FACTORS");
   return launch_lu_factor_solve(nb, n_pad, nrhs, d_A, lda, sys_stride, d_ipiv, d_info, d_work, work_bytes, (hipStream_t)stream,
                                 !(e && e[0] == '1'), /*symmetric=*/true);
+}
+
+int biem_lu_factor(int nb, int n_pad, double* d_A, long long lda, long long sys_stride, int* d_ipiv, int* d_info, void* d_work,
+                   size_t work_bytes, void* stream) {
+  NEED(d_A, "d_A"); NEED(d_ipiv, "d_ipiv"); NEED(d_info, "d_info"); NEED(d_work, "d_work");
+  return launch_lu_factor_solve(nb, n_pad, 0, d_A, lda, sys_stride, d_ipiv, d_info, d_work, work_bytes, (hipStream_t)stream, true, false);
+}
+
+int biem_ldlt_factor(int nb, int n_pad, double* d_A, long long lda, long long sys_stride, int* d_ipiv, int* d_info, void* d_work,
+                     size_t work_bytes, void* stream) {
+  NEED(d_A, "d_A"); NEED(d_ipiv, "d_ipiv"); NEED(d_info, "d_info"); NEED(d_work, "d_work");
+  return launch_lu_factor_solve(nb, n_pad, 0, d_A, lda, sys_stride, d_ipiv, d_info, d_work, work_bytes, (hipStream_t)stream, true, true);
+}
+
+int biem_lu_solve(int nb, int n_pad, int nrhs, const double* d_LU, long long lda, long long sys_stride, const int* d_ipiv, double* d_B,
+                  long long ldb, long long b_stride, void* stream) {
+  NEED(d_LU, "d_LU"); NEED(d_ipiv, "d_ipiv"); NEED(d_B, "d_B");
+  return launch_lu_solve(nb, n_pad, nrhs, d_LU, lda, sys_stride, d_ipiv, d_B, ldb, b_stride, (hipStream_t)stream);
 }
 
 int biem_density(const biem_plan* plan, int nb, int B, int nrhs, const double* d_x, long long sys_stride, long long elem_stride,

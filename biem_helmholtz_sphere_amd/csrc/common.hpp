@@ -87,10 +87,14 @@ int lu_npad(int N);
 size_t lu_workspace_bytes(int nb, int n_pad, int nrhs);
 int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_ipiv,
                            int* d_info, void* d_work, size_t work_bytes, hipStream_t st, bool keep_multipliers = true,
-                           bool symmetric = false);
+                           bool symmetric = false, bool amax_ready = false);
+// where the symmetric factorisation keeps max |A|, max |U| per system inside its workspace (unsigned 64-bit patterns of doubles)
+unsigned long long* lu_growth_slots(void* d_work, int nb, int n_pad);
 // [M | F] -> complex-symmetric [R W^H M W R^-1 | R W^H F] in place (inverse_on_solution: x = W R^-1 x~ on the solution columns)
 int launch_symmetrize(const biem_plan* p, int nb, int B, int nrhs, int n_pad, const double* d_tab, double* d_A, long long lda,
                       long long sys_stride, bool inverse_on_solution, hipStream_t st);
+int launch_lu_solve(int nb, int n_pad, int nrhs, const double* d_LU, long long lda, long long sys_stride, const int* d_ipiv, double* d_B,
+                    long long ldb, long long b_stride, hipStream_t st);
 int bench_mfma_f64(int iters, double* tflops, hipStream_t st);
 
 }  // namespace biem

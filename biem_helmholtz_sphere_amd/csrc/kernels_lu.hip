@@ -32,7 +32,56 @@ size_t lu_workspace_bytes(int nb, int n_pad, int nrhs) {
   // four 64-column panels (two K = 128 blocks = one K = 256 update) + the 64 x 64 operand I - L11^{-1} of the MFMA triangular solve
   // + the tile map of the triangular (symmetric) update: one int per lower-triangle tile of the largest trailing matrix
   const size_t T = (size_t)n_pad / NB;
-  return (size_t)nb * (4 * NB * (size_t)ldp_of(n_pad) + (size_t)NB * NB) * sizeof(cplx) + ((T * (T + 1) / 2 + 63) / 64) * 64 * sizeof(int);
+  // + two doubles per system: max |A| over what the symmetric factorisation reads and max |U| (a-posteriori growth check)
+  return (size_t)nb * (4 * NB * (size_t)ldp_of(n_pad) + (size_t)NB * NB) * sizeof(cplx) + ((T * (T + 1) / 2 + 63) / 64) * 64 * sizeof(int) +
+         (size_t)nb * 2 * sizeof(double);
+}
+
+// ---------------------------------------------------------------------------------------------
+// a-posteriori element growth of the symmetric factorisation (bounded multipliers alone do not bound it):
+// growth[s][0] = max |a_ij| over the part of A the factorisation reads, growth[s][1] = max |u_ij|, both as cabs1 = |re| + |im|.
+// Bit patterns of non-negative doubles order like unsigned integers and every NaN pattern lies above the finite ones, so a
+// 64-bit atomicMax keeps the maximum and a NaN sticks.  k_growth_check marks a system (info = -(n_pad + 1)) whose factor U grew
+// by more than GROWTH_MAX over A, or holds a non-finite entry; the caller re-solves it with the pivoted LU.
+// ---------------------------------------------------------------------------------------------
+constexpr double GROWTH_MAX = 1.0e3;
+__device__ inline double cabs1(cplx v) { return fabs(v.x) + fabs(v.y); }
+__device__ inline double nan_max(double a, double b) { return !(b <= a) ? b : a; }       // NaN in b wins; NaN in a stays
+__device__ inline void block_max_publish(double m, unsigned long long* dst) {              // 256-thread blocks
+  __shared__ double sm_max[4];
+  for (int o = 32; o > 0; o >>= 1) m = nan_max(m, __shfl_down(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sm_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = nan_max(nan_max(sm_max[0], sm_max[1]), nan_max(sm_max[2], sm_max[3]));
+    atomicMax(dst, (unsigned long long)__double_as_longlong(m));
+  }
+}
+// max |A| over the lower triangle and the diagonal 64 x 64 blocks: 8 rows per workgroup, coalesced along the row
+__global__ void __launch_bounds__(256) k_absmax_lower(const cplx* __restrict__ A, long long lda, long long sys_stride, int n_pad,
+                                                       unsigned long long* __restrict__ growth) {
+  const int s = blockIdx.y;
+  const cplx* As = A + (size_t)s * sys_stride;
+  double m = 0.0;
+  for (int r = 0; r < 8; ++r) {
+    const int i = blockIdx.x * 8 + r;
+    if (i >= n_pad) break;
+    const int cend = (i / NB + 1) * NB;
+    for (int c = threadIdx.x; c < cend; c += 256) m = nan_max(m, cabs1(As[(size_t)i * lda + c]));
+  }
+  block_max_publish(m, growth + 2 * (size_t)s);
+}
+unsigned long long* lu_growth_slots(void* d_work, int nb, int n_pad) {
+  const size_t T = (size_t)n_pad / NB;
+  cplx* Winv = (cplx*)d_work + (size_t)nb * 4 * NB * (size_t)ldp_of(n_pad);
+  int* tri = (int*)(Winv + (size_t)nb * NB * NB);
+  return (unsigned long long*)(tri + ((T * (T + 1) / 2 + 63) / 64) * 64);
+}
+__global__ void k_growth_check(int nb, int n_pad, const unsigned long long* __restrict__ growth, int* __restrict__ info, double limit) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nb) return;
+  const double amax = __longlong_as_double((long long)growth[2 * s]), umax = __longlong_as_double((long long)growth[2 * s + 1]);
+  if (!(umax <= limit * amax) && info[s] == 0) info[s] = -(n_pad + 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -920,20 +969,20 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
 }
 
 // C[row_begin:row_end, col_begin:col_end] -= P[0:kd]^T (rows of the region) * M[brow:brow+kd, cols of the region]
-static void launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, long long sys_stride, const cplx* Pw, long long ldp,
+static int launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, long long sys_stride, const cplx* Pw, long long ldp,
                                long long p_stride, int row_begin, int row_end, int col_begin, int col_end, int brow, int kd,
                                int prof_class = PK_GEMM, double prof_work = -1.0, cplx* pout = nullptr, long long pout_ld = 0,
                                long long pout_stride = 0, int pcol_tx = 0, const int* tri_map = nullptr) {
   const int tri = tri_map != nullptr;
   const int rrows = row_end - row_begin, rcols = col_end - col_begin;
-  if (rrows <= 0 || rcols <= 0) return;
+  if (rrows <= 0 || rcols <= 0) return BIEM_OK;
   TileGrid tg;
   tg.pout = pout; tg.pout_ld = pout_ld; tg.pout_stride = pout_stride; tg.pcol_tx = pcol_tx; tg.tri = tri;
   tg.ty_n = (rrows + BM3 - 1) / BM3; tg.tx_n = (rcols + BN3 - 1) / BN3;
   tg.per_sys = tri ? tg.ty_n * (tg.ty_n + 1) / 2 : tg.ty_n * tg.tx_n; tg.full_bands = tg.ty_n / 8; tg.ntiles = tg.per_sys * nb;
   tg.tri_map = tri_map; tg.tri_full = 32 * tg.full_bands * tg.full_bands + 4 * tg.full_bands;
   tg.per_sys_magic = ((1ULL << 40) + (unsigned long long)tg.per_sys - 1) / (unsigned long long)tg.per_sys;
-  if (tg.ntiles >= (1 << 25)) { set_error("biem_lu: more than 2^25 tiles in one update launch"); return; }   // unreachable: 2^25 tiles are 2 TB of matrix
+  if (tg.ntiles >= (1 << 25)) { set_error("biem_lu: more than 2^25 tiles in one update launch"); return BIEM_ERR_ARG; }   // unreachable: 2^25 tiles are 2 TB of matrix
   tg.row_begin = row_begin; tg.row_end = row_end; tg.col_begin = col_begin; tg.col_end = col_end; tg.brow = brow;
   const int cap = 512;                         // persistent grid: 2 workgroups per CU
   int want = (tg.ntiles + 7) / 8 * 8;          // one workgroup per tile up to the cap, multiple of 8
@@ -947,6 +996,7 @@ static void launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, l
     hipLaunchKernelGGL(k_gemm3m_pipe<192>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
   else
     hipLaunchKernelGGL(k_gemm3m_pipe<128>, dim3(grid), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, tg);
+  return BIEM_OK;
 }
 
 // W = I - L11^{-1} for the unit-lower 64 x 64 diagonal block of a panel, stored [k][i] (the MFMA A-operand order), so that
@@ -996,45 +1046,76 @@ __global__ void __launch_bounds__(64) k_swap_p(cplx* __restrict__ Pw, long long 
 // ---------------------------------------------------------------------------------------------
 // back substitution with U (row-major), block size BS
 // ---------------------------------------------------------------------------------------------
+// The right-hand sides are addressed as F[s * f_stride + row * ldf + q]: the augmented columns of the matrix itself
+// (F = A + n_pad, ldf = lda, f_stride = sys_stride) in the fused solve, a separate array in biem_lu_solve.
 // diagonal block: x = U[jr:jr+BS, jr:jr+BS]^{-1} y, one 64-thread workgroup per (system, rhs)
-__global__ void __launch_bounds__(64) k_back_diag(cplx* __restrict__ A, long long lda, long long sys_stride, int n_pad, int jr) {
+__global__ void __launch_bounds__(64) k_back_diag(const cplx* __restrict__ A, long long lda, long long sys_stride, cplx* __restrict__ F,
+                                                   long long ldf, long long f_stride, int jr) {
   __shared__ cplx sx;
   const int s = blockIdx.x, q = blockIdx.y, r = threadIdx.x;
-  cplx* As = A + (size_t)s * sys_stride;
-  const cplx* Urow = As + (size_t)(jr + r) * lda + jr;
-  cplx y = As[(size_t)(jr + r) * lda + n_pad + q];
+  const cplx* Urow = A + (size_t)s * sys_stride + (size_t)(jr + r) * lda + jr;
+  cplx* Fq = F + (size_t)s * f_stride + q;
+  cplx y = Fq[(size_t)(jr + r) * ldf];
   for (int c = BS - 1; c >= 0; --c) {
     if (r == c) { y = cmul(y, crecip(Urow[c])); sx = y; }
     __syncthreads();
     if (r < c) y = cfnma(Urow[c], sx, y);
     __syncthreads();
   }
-  As[(size_t)(jr + r) * lda + n_pad + q] = y;
+  Fq[(size_t)(jr + r) * ldf] = y;
 }
 
-// rows above: y[i] -= sum_c U[i][jr+c] x[jr+c]; one wave per row
-constexpr int BACK_ROWS = 16;   // rows per workgroup of the back-substitution update (4 per wave)
-__global__ void __launch_bounds__(256) k_back_update(cplx* __restrict__ A, long long lda, long long sys_stride, int n_pad, int nrhs, int jr) {
-  // y[i] -= U[i, jr:jr+64] . x[jr:jr+64] for the rows above the solved block.  The 64 solution values are strided by lda in
-  // memory (one cache line each): they are gathered ONCE per workgroup into LDS instead of once per row
+// forward counterpart (stored factors, biem_lu_solve): the 64 interchanges of the panel at column j on the right-hand side, then
+// y = L11^{-1} f with the unit-lower diagonal block; one 64-thread workgroup per (system, rhs)
+__global__ void __launch_bounds__(64) k_fwd_diag(const cplx* __restrict__ A, long long lda, long long sys_stride, const int* __restrict__ ipiv,
+                                                  int n_pad, cplx* __restrict__ F, long long ldf, long long f_stride, int j) {
+  __shared__ cplx sx;
+  const int s = blockIdx.x, q = blockIdx.y, r = threadIdx.x;
+  cplx* Fq = F + (size_t)s * f_stride + q;
+  if (r == 0) {
+    for (int c = 0; c < NB; ++c) {
+      const int p = ipiv[(size_t)s * n_pad + j + c];
+      if (p != j + c) { const cplx a = Fq[(size_t)(j + c) * ldf], b = Fq[(size_t)p * ldf]; Fq[(size_t)(j + c) * ldf] = b; Fq[(size_t)p * ldf] = a; }
+    }
+  }
+  __syncthreads();
+  const cplx* Lrow = A + (size_t)s * sys_stride + (size_t)(j + r) * lda + j;
+  cplx y = Fq[(size_t)(j + r) * ldf];
+  for (int c = 0; c < NB - 1; ++c) {
+    if (r == c) sx = y;
+    __syncthreads();
+    if (r > c) y = cfnma(Lrow[c], sx, y);
+    __syncthreads();
+  }
+  Fq[(size_t)(j + r) * ldf] = y;
+}
+
+// rows [row_begin, row_end): y[i] -= M[i, jr:jr+64] . x[jr:jr+64]; one wave per row (back substitution: the rows above the
+// solved block with M = U; forward substitution with stored factors: the rows below the panel with M = L)
+constexpr int BACK_ROWS = 16;   // rows per workgroup (4 per wave)
+__global__ void __launch_bounds__(256) k_back_update(const cplx* __restrict__ A, long long lda, long long sys_stride, cplx* __restrict__ F,
+                                                      long long ldf, long long f_stride, int nrhs, int jr, int row_begin, int row_end) {
+  // The 64 solution values are strided by ldf in memory (one cache line each): they are gathered ONCE per workgroup into LDS
+  // instead of once per row
   __shared__ cplx sx[BS];
   const int s = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  cplx* As = A + (size_t)s * sys_stride;
+  const cplx* As = A + (size_t)s * sys_stride;
+  cplx* Fs = F + (size_t)s * f_stride;
   for (int q = 0; q < nrhs; ++q) {
     if (q > 0) __syncthreads();
-    if (threadIdx.x < BS) sx[threadIdx.x] = As[(size_t)(jr + threadIdx.x) * lda + n_pad + q];
+    if (threadIdx.x < BS) sx[threadIdx.x] = Fs[(size_t)(jr + threadIdx.x) * ldf + q];
     __syncthreads();
     const cplx x = sx[lane];
 #pragma unroll
     for (int k = 0; k < BACK_ROWS / 4; ++k) {
-      const int i = blockIdx.x * BACK_ROWS + wave * (BACK_ROWS / 4) + k;
-      if (i >= jr) break;
+      const int i = row_begin + blockIdx.x * BACK_ROWS + wave * (BACK_ROWS / 4) + k;
+      if (i >= row_end) break;
       const cplx u = As[(size_t)i * lda + jr + lane];
       const cplx v = cmul(u, x);
       double vr = v.x, vi = v.y;
       for (int o = 32; o > 0; o >>= 1) { vr += __shfl_down(vr, o, 64); vi += __shfl_down(vi, o, 64); }
       if (lane == 0) {
-        cplx* y = As + (size_t)i * lda + n_pad + q;
+        cplx* y = Fs + (size_t)i * ldf + q;
         cplx t = *y;
         t.x -= vr; t.y -= vi;
         *y = t;
@@ -1105,7 +1186,8 @@ __global__ void __launch_bounds__(256) k_rhs_update(cplx* __restrict__ A, long l
 // |l_ic| <= 1 / rel for every multiplier; a violation marks the system (info = -(row + 1) of the panel's first row).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_diag_nopiv(cplx* __restrict__ Pj, long long ldp, long long p_stride, int n_pad, int j,
-                                                     cplx* __restrict__ Xinv, int* __restrict__ ipiv, int* __restrict__ info, double rel) {
+                                                     cplx* __restrict__ Xinv, int* __restrict__ ipiv, int* __restrict__ info, double rel,
+                                                     unsigned long long* __restrict__ growth) {
   // 256 threads: row r = tid & 63, part = tid >> 6 (one wave each).  Elimination: the four parts share the trailing columns of a
   // step (c2 = c+1+part, +4, ...).  Inverse: X = U11^{-1} by anti-diagonals d = c - k (entries of one d are independent), the
   // sum over m of an entry split over the four parts and reduced through LDS.
@@ -1150,7 +1232,9 @@ __global__ void __launch_bounds__(256) k_diag_nopiv(cplx* __restrict__ Pj, long 
     }
     __syncthreads();
   }
-  for (int c = part; c < NB; c += 4) Ps[(size_t)c * ldp + r] = a[c][r];
+  double um = 0.0;                                   // U11 = the entries on and above the diagonal (row r <= column c)
+  for (int c = part; c < NB; c += 4) { Ps[(size_t)c * ldp + r] = a[c][r]; if (r <= c) um = nan_max(um, cabs1(a[c][r])); }
+  block_max_publish(um, growth + 2 * (size_t)s + 1);
   cplx* Xo = Xinv + (size_t)s * NB * NB;
   for (int k = part; k < NB; k += 4) Xo[k * NB + r] = x[k][r];
   if (tid == 0 && bad && info[s] == 0) info[s] = -(j + 1);
@@ -1193,7 +1277,7 @@ __global__ void __launch_bounds__(256) k_panel_l21(cplx* __restrict__ Pj, long l
     for (int q = 0; q < 32; ++q) {
       Pr[(size_t)(cb + q) * ldp] = acc[q];
       const double v = fabs(acc[q].x) + fabs(acc[q].y);
-      lmax = v > lmax ? v : lmax;
+      if (!(v <= lmax)) lmax = v;                 // NaN-safe: a non-finite multiplier makes lmax NaN and marks the system
     }
   }
   if (!(lmax * rel <= 1.0) && info[s] == 0) info[s] = -(j + 1);
@@ -1201,18 +1285,28 @@ __global__ void __launch_bounds__(256) k_panel_l21(cplx* __restrict__ Pj, long l
 
 // U rows of a factored panel from its multipliers, symmetric path: U[j+i][c] = d_i L[c][i] for the columns c right of the panel
 // (A = L D L^T, so U = D L^T needs no triangular solve and no pending updates).  P is column-major: both sides are contiguous in c.
+// One workgroup: 256 columns x 16 of the panel's 64 rows; it also publishes max |U| of its entries (growth check).
 __global__ void __launch_bounds__(256) k_u_from_l(cplx* __restrict__ A, long long lda, long long sys_stride, const cplx* __restrict__ Pj,
-                                                   long long ldp, long long p_stride, int n_pad, int j) {
-  const int s = blockIdx.z, i = blockIdx.y;
+                                                   long long ldp, long long p_stride, int n_pad, int j, unsigned long long* __restrict__ growth) {
+  const int s = blockIdx.z;
   const int c = j + NB + blockIdx.x * 256 + threadIdx.x;
-  if (c >= n_pad) return;
-  const cplx* Pi = Pj + (size_t)s * p_stride + (size_t)i * ldp;
-  const cplx d = Pi[j + i];
-  A[(size_t)s * sys_stride + (size_t)(j + i) * lda + c] = cmul(d, Pi[c]);
+  double um = 0.0;
+  if (c < n_pad) {
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+      const int i = blockIdx.y * 16 + q;
+      const cplx* Pi = Pj + (size_t)s * p_stride + (size_t)i * ldp;
+      const cplx u = cmul(Pi[j + i], Pi[c]);
+      A[(size_t)s * sys_stride + (size_t)(j + i) * lda + c] = u;
+      um = nan_max(um, cabs1(u));
+    }
+  }
+  block_max_publish(um, growth + 2 * (size_t)s + 1);
 }
 
 int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_ipiv,
-                           int* d_info, void* d_work, size_t work_bytes, hipStream_t st, bool keep_multipliers, bool symmetric) {
+                           int* d_info, void* d_work, size_t work_bytes, hipStream_t st, bool keep_multipliers, bool symmetric,
+                           bool amax_ready) {
   if (nb <= 0 || n_pad <= 0) return BIEM_OK;
   if (n_pad % NB) { set_error("biem_lu: n_pad=%d is not a multiple of %d (use biem_lu_npad)", n_pad, NB); return BIEM_ERR_ARG; }
   if (nrhs < 0 || lda < n_pad + nrhs) { set_error("biem_lu: lda < n_pad + nrhs"); return BIEM_ERR_ARG; }
@@ -1229,10 +1323,19 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
   BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_inv_l11, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * NB * NB * sizeof(cplx))));
   BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_panel_l21, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NB * NB * sizeof(cplx))));
 
+  // status of the update launches (the lambdas below cannot return it themselves): the first failure is kept and returned
+  int gemm_rc = BIEM_OK;
+  auto gemm = [&](auto&&... a) { const int r = launch_gemm_stream(a...); if (r != BIEM_OK && gemm_rc == BIEM_OK) gemm_rc = r; };
   cplx* Winv = Pw + (size_t)nb * p_stride;      // 64 x 64 per system: I - L11^{-1} (LU) / U11^{-1} (symmetric path)
+  int* const tri_map_ws = (int*)(Winv + (size_t)nb * NB * NB);      // tile map of the triangular updates, then the growth slots
+  unsigned long long* growth = lu_growth_slots(d_work, nb, n_pad);  // [nb][2]: max |A|, max |U| (symmetric path)
   // BIEM_LDLT_PIVOT_REL (tests): acceptance threshold of the diagonal pivots (multipliers <= 1 / threshold); 1e30 rejects every system
   double nopiv = 0.0;
-  if (symmetric) { const char* e = getenv("BIEM_LDLT_PIVOT_REL"); nopiv = e ? atof(e) : NOPIV_REL; if (!(nopiv > 0.0)) nopiv = NOPIV_REL; }
+  double growth_max = GROWTH_MAX;     // BIEM_LDLT_GROWTH_MAX (tests): accepted max |U| / max |A|
+  if (symmetric) {
+    const char* e = getenv("BIEM_LDLT_PIVOT_REL"); nopiv = e ? atof(e) : NOPIV_REL; if (!(nopiv > 0.0)) nopiv = NOPIV_REL;
+    const char* g = getenv("BIEM_LDLT_GROWTH_MAX"); if (g && atof(g) > 0.0) growth_max = atof(g);
+  }
   // factor the 64-column panel at column j, multipliers into P columns [pc, pc + NB)
   auto panel = [&](int j, int pc, bool in_workspace = false) {
     cplx* Pj = Pw + (size_t)pc * ldp;
@@ -1242,7 +1345,7 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
       hipLaunchKernelGGL(k_panel_load, dim3((rows + TR - 1) / TR, nb), dim3(256), 0, st, A, lda, sys_stride, Pj, ldp, p_stride, n_pad, j);
     if (symmetric) {
       // no interchanges: diagonal block in one workgroup per system, then L21 = A21 U11^{-1} over all CUs
-      hipLaunchKernelGGL(k_diag_nopiv, dim3(nb), dim3(256), 0, st, Pj, ldp, p_stride, n_pad, j, Winv, d_ipiv, d_info, nopiv);
+      hipLaunchKernelGGL(k_diag_nopiv, dim3(nb), dim3(256), 0, st, Pj, ldp, p_stride, n_pad, j, Winv, d_ipiv, d_info, nopiv, growth);
       if (rows > NB)
         hipLaunchKernelGGL(k_panel_l21, dim3((rows - NB + 255) / 256, nb), dim3(256), NB * NB * sizeof(cplx), st, Pj, ldp, p_stride, n_pad, j,
                            Winv, d_info, nopiv);
@@ -1285,7 +1388,7 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
       hipLaunchKernelGGL(k_inv_l11, dim3(nb), dim3(64), 2 * NB * NB * sizeof(cplx), st, Pw + (size_t)pc * ldp, ldp, p_stride, j, Winv);
     }
     // A operand W[k][i], i = row - j: hand the kernel the base shifted by -j rows (only rows j .. j+63 are addressed)
-    launch_gemm_stream(st, nb, A, lda, sys_stride, Winv - j, NB, (long long)NB * NB, j, j + NB, col_begin, n_cols, j, NB, PK_TRSM, work);
+    gemm(st, nb, A, lda, sys_stride, Winv - j, NB, (long long)NB * NB, j, j + NB, col_begin, n_cols, j, NB, PK_TRSM, work);
   };
   // symmetric path: the panel's U rows over the matrix columns by transposition, over the right-hand sides by the solve
   const bool rhs_gemv = nrhs > 0 && nrhs <= 8;   // few right-hand sides: matrix-vector kernels instead of nearly empty MFMA tiles
@@ -1293,20 +1396,28 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     const int rcols = n_pad - (j + NB);
     if (rcols > 0) {
       ProfScope ps(PK_TRSM, st, 0.0);
-      hipLaunchKernelGGL(k_u_from_l, dim3((rcols + 255) / 256, NB, nb), dim3(256), 0, st, A, lda, sys_stride, Pw + (size_t)pc * ldp, ldp, p_stride, n_pad, j);
+      hipLaunchKernelGGL(k_u_from_l, dim3((rcols + 255) / 256, NB / 16, nb), dim3(256), 0, st, A, lda, sys_stride, Pw + (size_t)pc * ldp, ldp, p_stride, n_pad, j, growth);
     }
     if (rhs_gemv) {
       ProfScope ps(PK_TRSM, st, 0.0);
       hipLaunchKernelGGL(k_rhs_panel, dim3(nb, nrhs), dim3(64), 0, st, A, lda, sys_stride, Pw, ldp, p_stride, n_pad, j, jg, pc);
     } else if (nrhs > 0) {
-      if (pc > 0) launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, j, j + NB, n_pad, n_cols, jg, pc, PK_OTHER);
+      if (pc > 0) gemm(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, j, j + NB, n_pad, n_cols, jg, pc, PK_OTHER);
       trsm(j, pc, n_pad);
     }
   };
 
   if (symmetric) {
     // the tile map of the triangular updates (full bands of the largest trailing matrix), behind the panels and W
-    int* tri_map = (int*)(Winv + (size_t)nb * NB * NB);
+    int* tri_map = tri_map_ws;
+    {
+      // growth check, part 1: max |A| over what will be read (amax_ready: the caller's fill has already stored it), max |U| = 0
+      if (!amax_ready) {
+        hipLaunchKernelGGL(k_zero_int, dim3((4 * nb + 63) / 64), dim3(64), 0, st, (int*)growth, 4 * nb);
+        ProfScope ps(PK_SWAP, st, 0.0);
+        hipLaunchKernelGGL(k_absmax_lower, dim3((n_pad + 7) / 8, nb), dim3(256), 0, st, A, lda, sys_stride, n_pad, growth);
+      }
+    }
     {
       const int T = n_pad / NB, fb = T / 8, n_map = 32 * fb * fb + 4 * fb;
       if (n_map > 0) hipLaunchKernelGGL(k_tri_map, dim3((n_map + 255) / 256), dim3(256), 0, st, tri_map, n_map);
@@ -1321,21 +1432,21 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
         const int jq = J + q * NB;
         if (jq >= n_pad) break;
         // the panel's columns: all pending updates of the group (K = 64 q) for all rows below, delivered into the workspace
-        launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, jq, n_pad, jq, jq + NB, J, q * NB, PK_OTHER, -1.0,
+        gemm(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, jq, n_pad, jq, jq + NB, J, q * NB, PK_OTHER, -1.0,
                            Pw + (size_t)(q * NB) * ldp, ldp, p_stride, 0);
         panel(jq, q * NB, true);
         // right-hand sides of the panel's 64 rows: pending updates, then the solve; matrix columns: transposition
         u_rows_sym(jq, J, q * NB);
       }
       if (J + 4 * NB >= n_pad) break;
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 4 * NB, n_pad, J + 4 * NB, n_pad, J, 4 * NB, PK_GEMM, -1.0,
+      gemm(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 4 * NB, n_pad, J + 4 * NB, n_pad, J, 4 * NB, PK_GEMM, -1.0,
                          nullptr, 0, 0, 0, tri_map);
       if (rhs_gemv) {
         ProfScope ps(PK_OTHER, st, 0.0);
         hipLaunchKernelGGL(k_rhs_update, dim3((n_pad - (J + 4 * NB) + 255) / 256, nb, nrhs), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp,
                            p_stride, n_pad, J + 4 * NB, J, 4 * NB);
       } else if (nrhs > 0) {
-        launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 4 * NB, n_pad, n_pad, n_cols, J, 4 * NB, PK_OTHER);
+        gemm(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 4 * NB, n_pad, n_pad, n_cols, J, 4 * NB, PK_OTHER);
       }
     }
   } else
@@ -1355,43 +1466,74 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     for (int J = 0; J < n_pad; J += 4 * NB) {
       panel(J, 0); swap_right(J); trsm(J, 0);
       if (J + NB >= n_pad) break;                        // odd tail: nothing below the panel, forward elimination done
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + NB, n_pad, J + NB, J + 2 * NB, J, NB, PK_OTHER, -1.0,
+      gemm(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + NB, n_pad, J + NB, J + 2 * NB, J, NB, PK_OTHER, -1.0,
                          Pw + (size_t)NB * ldp, ldp, p_stride, 0);
       panel(J + NB, NB, true); swap_right(J + NB);
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + NB, J + 2 * NB, J + 2 * NB, n_cols, J, NB, PK_OTHER);
+      gemm(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + NB, J + 2 * NB, J + 2 * NB, n_cols, J, NB, PK_OTHER);
       trsm(J + NB, NB);
       if (J + 2 * NB >= n_pad) break;
       // T1: E's update of panel c's columns, ALL rows below E (the rows c's pivot search ranges over must be in one state);
       // the result goes straight into the workspace.  d's columns wait: they take E's and c's updates in one K = 192 pass.
       const int c_end = J + 3 * NB < n_pad ? J + 3 * NB : n_pad;
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 2 * NB, n_pad, J + 2 * NB, c_end, J, 2 * NB, PK_OTHER, -1.0,
+      gemm(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 2 * NB, n_pad, J + 2 * NB, c_end, J, 2 * NB, PK_OTHER, -1.0,
                          Pw + (size_t)(2 * NB) * ldp, ldp, p_stride, 0);
       panel(J + 2 * NB, 2 * NB, true); swap_right(J + 2 * NB);
       // T2c: E's update of c's 64 U rows right of c - only now, after c's interchanges: rows that an interchange can exchange
       // must carry the same updates, and the rows below still wait for the K = 256 update
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 2 * NB, c_end, c_end, n_cols, J, 2 * NB, PK_OTHER);
+      gemm(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 2 * NB, c_end, c_end, n_cols, J, 2 * NB, PK_OTHER);
       trsm(J + 2 * NB, 2 * NB);
       if (J + 3 * NB >= n_pad) break;
       // d's columns: E's and c's updates in one K = 192 pass, delivered into the workspace
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 3 * NB, n_pad, J + 3 * NB, J + 4 * NB, J, 3 * NB, PK_OTHER, -1.0,
+      gemm(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 3 * NB, n_pad, J + 3 * NB, J + 4 * NB, J, 3 * NB, PK_OTHER, -1.0,
                          Pw + (size_t)(3 * NB) * ldp, ldp, p_stride, 0);
       panel(J + 3 * NB, 3 * NB, true); swap_right(J + 3 * NB);
       // T2d and c's update of d's U rows in one K = 192 pass: [L_a L_b L_c] x [U_a; U_b; U_c]
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 3 * NB, J + 4 * NB, J + 4 * NB, n_cols, J, 3 * NB, PK_OTHER);
+      gemm(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 3 * NB, J + 4 * NB, J + 4 * NB, n_cols, J, 3 * NB, PK_OTHER);
       trsm(J + 3 * NB, 3 * NB);
-      launch_gemm_stream(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 4 * NB, n_pad, J + 4 * NB, n_cols, J, 4 * NB);
+      gemm(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 4 * NB, n_pad, J + 4 * NB, n_cols, J, 4 * NB);
     }
   }
+  if (symmetric) hipLaunchKernelGGL(k_growth_check, dim3((nb + 63) / 64), dim3(64), 0, st, nb, n_pad, growth, d_info, growth_max);
   BIEM_LAUNCHCHK();
+  if (gemm_rc != BIEM_OK) return gemm_rc;
   if (nrhs > 0) {
     ProfScope ps(PK_BACK, st, 4.0 * (double)nb * n_pad * (double)n_pad * nrhs);
     for (int jr = n_pad - BS; jr >= 0; jr -= BS) {
-      hipLaunchKernelGGL(k_back_diag, dim3(nb, nrhs), dim3(64), 0, st, A, lda, sys_stride, n_pad, jr);
+      hipLaunchKernelGGL(k_back_diag, dim3(nb, nrhs), dim3(64), 0, st, A, lda, sys_stride, A + n_pad, lda, sys_stride, jr);
       if (jr > 0)
-        hipLaunchKernelGGL(k_back_update, dim3((jr + BACK_ROWS - 1) / BACK_ROWS, nb), dim3(256), 0, st, A, lda, sys_stride, n_pad, nrhs, jr);
+        hipLaunchKernelGGL(k_back_update, dim3((jr + BACK_ROWS - 1) / BACK_ROWS, nb), dim3(256), 0, st, A, lda, sys_stride, A + n_pad, lda,
+                           sys_stride, nrhs, jr, 0, jr);
     }
     BIEM_LAUNCHCHK();
   }
+  return BIEM_OK;
+}
+
+// Solve with the stored factors of launch_lu_factor_solve(keep_multipliers = true): the multipliers of a panel are stored in the
+// row order its own 64 interchanges left (later panels' interchanges are not applied to them), so the forward substitution
+// interleaves interchanges and eliminations panel by panel; L D L^T factors are the case ipiv = identity, U = D L^T.
+int launch_lu_solve(int nb, int n_pad, int nrhs, const double* d_LU, long long lda, long long sys_stride, const int* d_ipiv, double* d_B,
+                    long long ldb, long long b_stride, hipStream_t st) {
+  if (nb <= 0 || n_pad <= 0 || nrhs <= 0) return BIEM_OK;
+  if (n_pad % NB) { set_error("biem_lu_solve: n_pad=%d is not a multiple of %d (use biem_lu_npad)", n_pad, NB); return BIEM_ERR_ARG; }
+  if (lda < n_pad || ldb < nrhs) { set_error("biem_lu_solve: lda < n_pad or ldb < nrhs"); return BIEM_ERR_ARG; }
+  if (nb > 65535 || nrhs > 65535) { set_error("biem_lu_solve: at most 65535 systems / right-hand sides per call (got %d / %d)", nb, nrhs); return BIEM_ERR_ARG; }
+  const cplx* A = (const cplx*)d_LU;
+  cplx* F = (cplx*)d_B;
+  for (int j = 0; j < n_pad; j += NB) {
+    hipLaunchKernelGGL(k_fwd_diag, dim3(nb, nrhs), dim3(64), 0, st, A, lda, sys_stride, d_ipiv, n_pad, F, ldb, b_stride, j);
+    const int below = n_pad - (j + NB);
+    if (below > 0)
+      hipLaunchKernelGGL(k_back_update, dim3((below + BACK_ROWS - 1) / BACK_ROWS, nb), dim3(256), 0, st, A, lda, sys_stride, F, ldb, b_stride,
+                         nrhs, j, j + NB, n_pad);
+  }
+  for (int jr = n_pad - BS; jr >= 0; jr -= BS) {
+    hipLaunchKernelGGL(k_back_diag, dim3(nb, nrhs), dim3(64), 0, st, A, lda, sys_stride, F, ldb, b_stride, jr);
+    if (jr > 0)
+      hipLaunchKernelGGL(k_back_update, dim3((jr + BACK_ROWS - 1) / BACK_ROWS, nb), dim3(256), 0, st, A, lda, sys_stride, F, ldb, b_stride,
+                         nrhs, jr, 0, jr);
+  }
+  BIEM_LAUNCHCHK();
   return BIEM_OK;
 }
 

@@ -3,14 +3,20 @@
 //   far  : no radial factor, times (-i)^n e^{-i k x.c_b} / (i k)^{(d-1)/2}; Y is still taken at dir(x - c_b),
 //          exactly as the reference does (_biem.py:885,930-959)
 //   NaN fill where the point is inside a ball (outer) / outside (inner)                          (_biem.py:971-976)
+//   kind = "inner": the points left valid lie INSIDE the spheres (r <= rho), where the layer potentials of a density Y_h on
+//   |y| = rho expand in the regular functions: slc_in = i k^{d-2} rho^{d-1} h_n(k rho) j_n(k r), dlc_in = i k^{d-1} rho^{d-1}
+//   h_n'(k rho) j_n(k r) (j and h exchange roles across the sphere; potential_coef(x_abs = r, y_abs = rho) of the un-vendored
+//   ultrasphere presumably selects it - parity unpinned, no reference fixture has kind = "inner").  The exterior form is
+//   singular at r -> 0 and is not the potential there.  tests: jump relation u(rho+) - u(rho-) = density . Y, regularity at
+//   r = 0, Helmholtz residual inside the ball.
 #include "common.hpp"
 
 namespace biem {
 
 constexpr int kMaxRadU = 320;
 
-// c[s][b][h] = density * blc_{n(h)}(rho_b): one wave per (system, ball)
-__global__ void __launch_bounds__(64) k_uscat_coef(int d, int H, int n_end, const int* __restrict__ deg, int B,
+// c[s][b][h] = density * blc_{n(h)}(rho_b) (inner: the interior coefficient with h_n, h_n' at k rho): one wave per (system, ball)
+__global__ void __launch_bounds__(64) k_uscat_coef(int d, int H, int n_end, const int* __restrict__ deg, int B, int inner,
                                                     const cplx* __restrict__ k, const double* __restrict__ eta,
                                                     const double* __restrict__ radii, int geom_batched,
                                                     const cplx* __restrict__ dens, cplx* __restrict__ c) {
@@ -26,8 +32,8 @@ __global__ void __launch_bounds__(64) k_uscat_coef(int d, int H, int n_end, cons
     double rp = 1.0; for (int q = 0; q < d - 1; ++q) rp *= rho;
     cplx kd2 = make_double2(1.0, 0.0); for (int q = 0; q < d - 2; ++q) kd2 = cmul(kd2, kk);
     for (int n = 0; n < n_end; ++n) {
-      const cplx j = sJ[n];
-      const cplx kjp = cmul(kk, csub(cscale(cmul(ix, j), (double)n), sJ[n + 1]));
+      const cplx j = inner ? sH[n] : sJ[n];
+      const cplx kjp = cmul(kk, csub(cscale(cmul(ix, j), (double)n), inner ? sH[n + 1] : sJ[n + 1]));
       sB[n] = cscale(cmul(kd2, make_double2(et * j.x - kjp.y, et * j.y + kjp.x)), rp);   // blc = k^{d-2} rho^{d-1} (eta j + i k j')
     }
   }
@@ -71,6 +77,11 @@ __global__ void __launch_bounds__(256) k_uscat(int tree, int d, int H, int n_end
       if (lane == 0 && !far) {
         if ((!inner && r < rho) || (inner && r > rho)) atomicOr(&sBad, 1);
         if (r > 0.0) radial_jh(d, n_end - 1, cscale(kk, r), sJ[wave], sH[wave]);
+        else {   // centre of a ball (inner kind): z_n(0) = delta_{n0} sqrt(pi/2) 2^{1-d/2} / Gamma(d/2); the exterior form has no value there
+          const double z0 = d == 2 ? kSqrtHalfPi : d == 3 ? 1.0 : 0.5 * kSqrtHalfPi;
+          const double qn = __longlong_as_double(0x7ff8000000000000LL);
+          for (int n = 0; n < n_end; ++n) { sJ[wave][n] = make_double2(n == 0 ? z0 : 0.0, 0.0); sH[wave][n] = make_double2(qn, qn); }
+        }
       }
     }
     __syncthreads();
@@ -88,7 +99,7 @@ __global__ void __launch_bounds__(256) k_uscat(int tree, int d, int H, int n_end
           int q = n & 3;
           rad = q == 0 ? make_double2(1, 0) : q == 1 ? make_double2(0, -1) : q == 2 ? make_double2(-1, 0) : make_double2(0, 1);
         } else {
-          rad = sH[wave][n];
+          rad = inner ? sJ[wave][n] : sH[wave][n];
         }
         cplx v = cmul(cmul(cs[h], rad), make_double2(yr, yi));
         ar += v.x; ai += v.y;
@@ -128,7 +139,8 @@ int launch_uscat(const biem_plan* p, int nb, int B, int P, const double* d_k, co
   size_t need = (size_t)nb * B * p->H * sizeof(cplx);
   if (work_bytes < need) { set_error("biem_uscat: workspace too small"); return BIEM_ERR_ARG; }
   cplx* c = (cplx*)d_work;
-  hipLaunchKernelGGL(k_uscat_coef, dim3(B, nb), dim3(64), 0, st, p->d, p->H, p->n_end, p->d_deg, B, (const cplx*)d_k, d_eta, d_radii,
+  hipLaunchKernelGGL(k_uscat_coef, dim3(B, nb), dim3(64), 0, st, p->d, p->H, p->n_end, p->d_deg, B,
+                     (flags & BIEM_USCAT_KIND_INNER) && !(flags & BIEM_USCAT_FAR_FIELD) ? 1 : 0, (const cplx*)d_k, d_eta, d_radii,
                      geom_batched, (const cplx*)d_density, c);
   BIEM_LAUNCHCHK();
   hipLaunchKernelGGL(k_uscat, dim3(P, nb), dim3(256), (size_t)B * sizeof(cplx), st, p->tree, p->d, p->H, p->n_end, p->d_labels,

@@ -56,6 +56,8 @@ extern "C" {
 typedef struct biem_plan biem_plan; /* opaque: host+device tables of one (tree, n_end) */
 
 int biem_version(void);
+/* hash of the csrc/ + include/ sources the library was built from (the Python loader rebuilds a library whose hash differs) */
+const char* biem_build_id(void);
 const char* biem_last_error(void);
 /* number of visible HIP devices; BIEM_ERR_NO_DEVICE if none */
 int biem_device_count(int* n);
@@ -128,12 +130,29 @@ size_t biem_lu_workspace_bytes(int nb, int n_pad, int nrhs);   /* panels of a gr
 int biem_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride,
                          int* d_ipiv /*[nb][n_pad]*/, int* d_info /*[nb]*/, void* d_work, size_t work_bytes, void* stream);
 
+/* Factor now, solve later (the reference's btensorsolve has no such split: linalg.solve factors again for every call, _biem.py:797).
+ * biem_lu_factor leaves in A the factor U (on and above the diagonal) and the multipliers (below), d_ipiv the interchanges:
+ * row j was exchanged with row ipiv[j] >= j when column j was eliminated; the multipliers of a 64-column panel are stored in the
+ * row order that panel's own interchanges left (LINPACK style: later interchanges are NOT applied to earlier multipliers), which
+ * is what biem_lu_solve expects.  biem_lu_solve overwrites B (row-major [Npad][ldb] per system, nrhs <= ldb columns, system s at
+ * d_B + 2*s*b_stride doubles; rows N..Npad-1 of an identity-padded system must hold zeros) with the solutions; it needs no
+ * workspace and may be called any number of times.  d_info as in biem_lu_factor_solve. */
+int biem_lu_factor(int nb, int n_pad, double* d_A, long long lda, long long sys_stride, int* d_ipiv /*[nb][n_pad]*/, int* d_info /*[nb]*/,
+                   void* d_work, size_t work_bytes /* biem_lu_workspace_bytes(nb, n_pad, 0) */, void* stream);
+int biem_lu_solve(int nb, int n_pad, int nrhs, const double* d_LU, long long lda, long long sys_stride, const int* d_ipiv,
+                  double* d_B, long long ldb, long long b_stride, void* stream);
+/* the same split for complex-symmetric systems (see biem_ldlt_factor_solve below): A <- L (unit lower, below the diagonal) and
+ * U = D L^T (on and above), ipiv = identity; solve with biem_lu_solve.  d_info[s] < 0: rejected, use biem_lu_factor. */
+int biem_ldlt_factor(int nb, int n_pad, double* d_A, long long lda, long long sys_stride, int* d_ipiv, int* d_info, void* d_work,
+                     size_t work_bytes, void* stream);
+
 /* Complex-SYMMETRIC systems (A = A^T, not Hermitian): A = L D L^T with the diagonal as pivots, no interchanges.  Same layout,
  * workspace and kernels as biem_lu_factor_solve; a panel's U rows are its transposed multipliers and the K = 256 updates run
  * over the lower triangle of tiles only (half the flops).  Only the lower triangle (and the diagonal 64 x 64 blocks) of A is
  * read.  d_info[s] = -(row+1), `row` = first row of the 64-column panel in which a diagonal entry was below 0.5 x the largest
- * entry of its (updated) column, i.e. a multiplier exceeded 2 (partial pivoting guarantees 1; or NaN):
- * the result of that system is not to be trusted and the caller re-solves it with biem_lu_factor_solve. */
+ * entry of its (updated) column, i.e. a multiplier exceeded 2 (partial pivoting guarantees 1; or NaN);
+ * d_info[s] = -(Npad+1): a-posteriori growth check failed, max |U| > 1e3 max |A| (|.| = |re| + |im|, A = the part read) or a
+ * non-finite entry in U: the result of that system is not to be trusted and the caller re-solves it with biem_lu_factor_solve. */
 int biem_ldlt_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride,
                            int* d_ipiv /*[nb][n_pad], identity on return*/, int* d_info /*[nb]*/, void* d_work, size_t work_bytes,
                            void* stream);

@@ -723,7 +723,12 @@ def uscat(res: OracleResult, x, far_field: bool = False, per_ball: bool = False)
         rs = np.where(r > 0, r, 1.0)
         Y = tr.harmonics(rel / rs[:, None], n_end)        # [H, P]
         # blc from the stored (k, eta, rho) -- density * SD_coef * Y  (_biem.py:896-917, 961)
-        j, _, jp, _ = radial_h(n_end - 1, d, k * res.radii[b])
+        j, hb, jp, hbp = radial_h(n_end - 1, d, k * res.radii[b])
+        inner = res.kind == "inner" and not far_field
+        if inner:
+            # points with r <= rho: the layer potentials expand in the regular functions, j and h exchange roles
+            # (slc_in = i k^{d-2} rho^{d-1} h_n(k rho) j_n(k r), dlc_in = i k^{d-1} rho^{d-1} h_n'(k rho) j_n(k r))
+            j, jp = hb, hbp
         blc = 1j * k ** (d - 1) * res.radii[b] ** (d - 1) * jp - 1j * eta * (1j * k ** (d - 2) * res.radii[b] ** (d - 1) * j)
         c = res.density[b] * blc[deg]
         if far_field:
@@ -733,8 +738,11 @@ def uscat(res: OracleResult, x, far_field: bool = False, per_ball: bool = False)
         else:
             hn = np.empty((n_end, xs.shape[0]), dtype=np.complex128)
             for p, rp in enumerate(rs):
-                _, hh, _, _ = radial_h(n_end - 1, d, k * rp)
-                hn[:, p] = hh
+                jj, hh, _, _ = radial_h(n_end - 1, d, k * rp)
+                hn[:, p] = jj if inner else hh
+                if inner and r[p] == 0.0:      # centre of the ball: z_n(0) = delta_n0 sqrt(pi/2) 2^{1-d/2} / Gamma(d/2)
+                    hn[:, p] = 0.0
+                    hn[0, p] = {2: np.sqrt(np.pi / 2), 3: 1.0, 4: 0.5 * np.sqrt(np.pi / 2)}[d]
             out[:, b] = np.sum(c[:, None] * hn[deg, :] * Y, axis=0)
             if res.kind == "outer":
                 bad |= r < res.radii[b]

@@ -671,3 +671,206 @@ def test_ldlt_natural_fallback_close_spheres(amd, monkeypatch):
         if solver == "ldlt":
             assert impl._last_solve_stats == {"ldlt_systems": 2, "lu_systems": 1}
     assert np.max(np.abs(out["ldlt"] - out["lu"]) / np.abs(out["lu"])) < 1e-12
+
+
+# ---------------------------------------------------------------------------- round 2: growth check, factor / solve split, inner kind
+@pytest.mark.gpu
+def test_ldlt_growth_check_measures_max_u_over_max_a(lib, monkeypatch):
+    """The a-posteriori growth check of the symmetric path: max |U| / max |A| (|.| = |re| + |im|, A = the part read) computed on
+    the device equals the NumPy L D L^T without interchanges - a limit 1 % below it marks the system (info = -(Npad + 1)), 1 %
+    above does not; a NaN in the matrix marks the system at the default limit."""
+    l, L = lib
+    N, npad = 200, 256
+    rng = np.random.default_rng(5)
+    E = (rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))) * (0.12 / np.sqrt(N))
+    As = np.eye(N) * (1.0 + 0.2j) + E + E.T
+    M = As.copy()                                       # reference factorisation: U ends up in the upper triangle
+    for c in range(N):
+        M[c + 1:, c] /= M[c, c]
+        M[c + 1:, c + 1:] -= np.outer(M[c + 1:, c], M[c, c + 1:])
+    cabs1 = lambda z: np.abs(z.real) + np.abs(z.imag)
+    ratio = cabs1(np.triu(M)).max() / cabs1(As).max()
+
+    def run(limit, poison=False):
+        if limit is None:
+            monkeypatch.delenv("BIEM_LDLT_GROWTH_MAX", raising=False)
+        else:
+            monkeypatch.setenv("BIEM_LDLT_GROWTH_MAX", repr(limit))
+        A = np.zeros((2, npad, npad + 8), dtype=np.complex128)
+        A[:, :N, :N] = As
+        A[:, np.arange(N, npad), np.arange(N, npad)] = 1.0
+        A[:, :N, npad] = 1.0
+        if poison:
+            A[1, 150, 20] = np.nan
+        dA = _dev(A, torch.complex128)
+        ipiv = torch.zeros((2, npad), dtype=torch.int32, device="cuda")
+        info = torch.zeros(2, dtype=torch.int32, device="cuda")
+        wb = l.biem_lu_workspace_bytes(2, npad, 1)
+        work = torch.empty(wb, dtype=torch.uint8, device="cuda")
+        L.check(l.biem_ldlt_factor_solve(2, npad, 1, dA.data_ptr(), npad + 8, npad * (npad + 8), ipiv.data_ptr(), info.data_ptr(), work.data_ptr(), wb, None))
+        torch.cuda.synchronize()
+        return info.cpu().tolist()
+
+    assert run(0.99 * ratio) == [-(npad + 1)] * 2
+    assert run(1.01 * ratio) == [0, 0]
+    bad = run(None, poison=True)
+    assert bad[0] == 0 and bad[1] < 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,nb,nrhs,sym", [(64, 2, 1, False), (300, 2, 3, False), (576, 1, 2, False), (1000, 2, 1, False),
+                                           (150, 2, 2, True), (700, 1, 5, True)])
+def test_factor_now_solve_later(lib, N, nb, nrhs, sym):
+    """biem_lu_factor / biem_ldlt_factor keep the factors (and interchanges); biem_lu_solve serves right-hand sides that arrive
+    later, any number of times, without a workspace - against numpy.linalg.solve on Gaussian (heavily pivoting) and
+    complex-symmetric matrices."""
+    l, L = lib
+    rng = np.random.default_rng(N + 31)
+    npad = l.biem_lu_npad(N)
+    if sym:
+        E = (rng.normal(size=(nb, N, N)) + 1j * rng.normal(size=(nb, N, N))) * (0.12 / np.sqrt(N))
+        As = np.eye(N)[None] * (1.0 + 0.2j) + E + np.swapaxes(E, 1, 2)
+    else:
+        As = rng.normal(size=(nb, N, N)) + 1j * rng.normal(size=(nb, N, N))
+    A = np.zeros((nb, npad, npad), dtype=np.complex128)
+    A[:, :N, :N] = As
+    A[:, np.arange(N, npad), np.arange(N, npad)] = 1.0
+    dA = _dev(A, torch.complex128)
+    ipiv = torch.zeros((nb, npad), dtype=torch.int32, device="cuda")
+    info = torch.ones(nb, dtype=torch.int32, device="cuda")
+    wb = l.biem_lu_workspace_bytes(nb, npad, 0)
+    work = torch.empty(wb, dtype=torch.uint8, device="cuda")
+    factor = l.biem_ldlt_factor if sym else l.biem_lu_factor
+    L.check(factor(nb, npad, dA.data_ptr(), npad, npad * npad, ipiv.data_ptr(), info.data_ptr(), work.data_ptr(), wb, None))
+    torch.cuda.synchronize()
+    assert info.cpu().tolist() == [0] * nb
+    del work                                          # the solve needs none
+    if sym:
+        assert (ipiv.cpu().numpy() == np.arange(npad)[None]).all()
+    for trial in range(2):
+        ldb = nrhs + trial                            # a leading dimension larger than nrhs is allowed
+        Fs = rng.normal(size=(nb, N, nrhs)) + 1j * rng.normal(size=(nb, N, nrhs))
+        Bm = np.zeros((nb, npad, ldb), dtype=np.complex128)
+        Bm[:, :N, :nrhs] = Fs
+        dB = _dev(Bm, torch.complex128)
+        L.check(l.biem_lu_solve(nb, npad, nrhs, dA.data_ptr(), npad, npad * npad, ipiv.data_ptr(), dB.data_ptr(), ldb, npad * ldb, None))
+        torch.cuda.synchronize()
+        X = dB.cpu().numpy()
+        assert np.abs(X[:, N:, :nrhs]).max(initial=0.0) == 0
+        for s in range(nb):
+            Xo = np.linalg.solve(As[s], Fs[s])
+            assert np.abs(X[s, :N, :nrhs] - Xo).max() / np.abs(Xo).max() < (1e-12 if sym else 1e-9), (N, s, trial)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tree", ["a", "ba", "bba"])
+def test_kind_inner_interior_expansion(amd, tree):
+    """kind="inner" (reference :971-976 keeps the points with r <= rho): there the layer potentials expand in the REGULAR
+    functions.  No reference fixture covers it (parity unpinned), so besides the oracle the test checks what defines the
+    interior potential: the jump relation across the sphere, u(rho+) - u(rho-) = sum_h density_h Y_h (double layer jumps by the
+    density, single layer is continuous), a finite value at the centre, the Helmholtz equation inside, and the NaN mask."""
+    tr = O.tree(tree)
+    d = tr.d
+    k, n_end, eta = 2.0, 7, 1.3
+    cen, rad = np.zeros((1, d)), np.array([1.0])
+    e = np.zeros(d); e[0] = 1.0; e[1] = 0.3
+    c = amd.create_from_branching_types(tree)
+    uin, ugr = amd.plane_wave(k=_dev(k), direction=_dev(e))
+    kw = dict(centers=_dev(cen), radii=_dev(rad), k=_dev(k), eta=_dev(eta), n_end=n_end, alpha=1.0, beta=0.4, uin=uin, uin_grad=ugr)
+    cin, cout = amd.biem(c, kind="inner", **kw), amd.biem(c, kind="outer", **kw)
+    assert torch.equal(cin.density, cout.density)           # the reference's solve does not depend on `kind`
+    uo_in, ug_in = O.plane_wave(k, e)
+    res = O.solve_biem(tree, centers=cen, radii=rad, k=k, n_end=n_end, eta=eta, alpha=1.0, beta=0.4, uin=uo_in, uin_grad=ug_in, kind="inner")
+    rng = np.random.default_rng(3)
+    pts = rng.normal(size=(12, d))
+    pts *= (rng.uniform(0.05, 0.95, size=12) / np.linalg.norm(pts, axis=1))[:, None]
+    pts[0] = 0.0                                            # the centre of the ball
+    u = cin.uscat(_dev(pts.T)).cpu().numpy()
+    ref = O.uscat(res, pts)
+    assert np.isfinite(u).all() and np.max(np.abs(u - ref) / np.abs(ref)) < 1e-10
+    out_pts = pts[1:4] / np.linalg.norm(pts[1:4], axis=1)[:, None] * 1.7
+    assert np.isnan(cin.uscat(_dev(out_pts.T)).cpu().numpy()).all() and np.isnan(cout.uscat(_dev(pts[1:4].T)).cpu().numpy()).all()
+    # jump relation on the sphere (r == rho exactly: valid for both kinds, masks are strict)
+    xs = np.zeros((3, d)); xs[0, 0] = 1.0; xs[1, 1] = -1.0; xs[2, d - 1] = 1.0
+    jump = cout.uscat(_dev(xs.T)).cpu().numpy() - cin.uscat(_dev(xs.T)).cpu().numpy()
+    Y = tr.harmonics(xs, n_end)                             # [H, P]
+    want = cin.density.cpu().numpy().reshape(-1) @ Y
+    assert np.max(np.abs(jump - want)) < 1e-11 * np.max(np.abs(want))
+    # Helmholtz equation inside: 2d-point stencil, h = 5e-3 (truncation ~ h^2 k^4 / 12)
+    h, x0 = 5e-3, pts[5]
+    st = np.concatenate([[x0]] + [[x0 + h * np.eye(d)[i], x0 - h * np.eye(d)[i]] for i in range(d)])
+    us = cin.uscat(_dev(st.T)).cpu().numpy()
+    lap = (us[1:].sum() - 2 * d * us[0]) / h**2
+    assert abs(lap + k * k * us[0]) < 2e-4 * k * k * abs(us[0])
+
+
+@pytest.mark.gpu
+def test_accuracy_sweep_driver_rows_vs_reference_csv(amd, golden_dir, tmp_path):
+    """The accuracy-style sweep (reference cli.py:188-271: grids of balls, operator k swept with the incident wave kept at
+    k = 1) writes the reference's schema; its rows equal the committed accuracy_n_balls_a.csv / accuracy_k_ba.csv rows."""
+    from biem_helmholtz_sphere_amd import sweep
+
+    out = tmp_path / "acc_a.csv"
+    sweep.main(["accuracy", "--out", str(out), "--types", "a", "--n-balls", "4,16", "--k", "1", "--n-end", "1,3,6,13,32"])
+    with open(out) as f:
+        assert f.readline() == sweep.ACCURACY_HEADER
+    with open(out) as f:
+        mine = {(r["branching_types"], int(r["n_end"]), int(r["n_balls"])): complex(r["uscat"]) for r in csv.DictReader(f)}
+    assert len(mine) == 10
+    n = 0
+    with open(os.path.join(golden_dir, "accuracy_n_balls_a.csv")) as f:
+        hdr = f.readline()
+        assert hdr == sweep.ACCURACY_HEADER
+        f.seek(0)
+        for r in csv.DictReader(f):
+            key = (r["branching_types"], int(r["n_end"]), int(r["n_balls"]))
+            if key in mine:
+                assert abs(mine[key] - complex(r["uscat"])) < 1e-11, key
+                n += 1
+    assert n == 10
+    out = tmp_path / "acc_ba.csv"
+    kvals = [1.0, 2.0 ** 0.5, 4.0, 2.0 ** 3.5]
+    sweep.main(["accuracy", "--out", str(out), "--types", "ba", "--n-balls", "2", "--k", ",".join(repr(v) for v in kvals), "--n-end", "2,6,12,20"])
+    with open(out) as f:
+        mine = {(r["branching_types"], int(r["n_end"]), round(float(r["k"]), 9)): complex(r["uscat"]) for r in csv.DictReader(f)}
+    n = 0
+    with open(os.path.join(golden_dir, "accuracy_k_ba.csv")) as f:
+        for r in csv.DictReader(f):
+            key = (r["branching_types"], int(r["n_end"]), round(float(r["k"]), 9))
+            if key in mine:
+                assert abs(mine[key] - complex(r["uscat"])) < 1e-11 * max(1.0, abs(complex(r["uscat"]))), key
+                n += 1
+    assert n >= 12
+
+
+@pytest.mark.gpu
+def test_sharded_solve_on_rccl_world_size_one(amd):
+    """_dist.biem_sharded with the real biem() on the `nccl` (= RCCL) backend at world size 1: geometry broadcast, shard, solve,
+    all-gather of the densities - equal to a plain biem() call."""
+    import socket
+
+    import torch.distributed as dist
+
+    from biem_helmholtz_sphere_amd import _dist
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        c = amd.create_from_branching_types("ba")
+        cen = _dev(O.grid_centers(1, 3))
+        rad = _dev(np.ones(4))
+        ks = _dev(np.linspace(0.7, 2.0, 5))
+        dirs = np.zeros((3, 5)); dirs[0] = 1.0
+
+        def incident(k_loc, sl):
+            return amd.plane_wave(k=k_loc, direction=_dev(dirs[:, sl]))
+
+        res, full = _dist.biem_sharded(c, centers=cen, radii=rad, k=ks, n_end=5, incident=incident, device=torch.device("cuda", 0))
+        uin, _ = amd.plane_wave(k=ks, direction=_dev(dirs))
+        plain = amd.biem(c, centers=cen[None], radii=rad[None], k=ks, n_end=5, uin=uin)
+        assert full.shape == plain.density.shape and torch.equal(full, plain.density)
+        assert torch.equal(res.density, plain.density)
+    finally:
+        dist.destroy_process_group()

@@ -77,6 +77,45 @@ def test_input_validation_messages():
         v(c, np.zeros((2, 3)), np.ones(2), np.asarray(1.0), np.asarray(1.0 + 1.0j), 1.0, 0.0)
 
 
+def test_user_warnings_of_the_input_check():
+    """Reference _biem.py:269-285: eta == 0 and (Im k < 0 or eta Re k < 0) warn (texts are API, run-together words included)."""
+    import warnings
+
+    w = _biem._warn_biem_inputs
+    with pytest.warns(UserWarning, match="The solution may be incorrectif k is an eigenvalue for laplacianon the interior region withNeumann boundary condition."):
+        w(np.asarray([1.0, 2.0]), np.asarray([1.0, 0.0]))
+    with pytest.warns(UserWarning, match=r"The solution may be incorrectif not \(Im k >= 0 and eta Re k >= 0\)\."):
+        w(np.asarray(1.0 - 0.1j), np.asarray(1.0))
+    with pytest.warns(UserWarning, match="eta Re k >= 0"):
+        w(np.asarray([1.0, 2.0]), np.asarray([1.0, -0.5]))
+    with pytest.warns(UserWarning, match="eta Re k >= 0"):
+        w(np.asarray(-1.0), None)                       # eta defaults to 1
+    import torch
+
+    with pytest.warns(UserWarning, match="eta Re k >= 0"):
+        w(torch.tensor([1.0, 2.0]), torch.tensor([-1.0, 1.0]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        w(np.asarray([0.5, 8.0]), None)
+        w(np.asarray(1.0 + 0.3j), np.asarray(2.0))
+        w(torch.tensor([0.5, 8.0]), torch.tensor([1.0, 1.0]))
+
+
+def test_isa_check_of_the_built_library():
+    """The LDS-DMA ring of k_gemm3m_pipe counts vector-memory instructions by hand: the build pins no scratch, no VGPR spills,
+    96 MFMAs in the chunk loop and the reviewed set of vector-memory instructions (runs on the CPU: llvm-objdump on the .so)."""
+    from biem_helmholtz_sphere_amd import _build
+
+    _lib.load()
+    assert not _build.is_stale() and _build.built_hash() == _build.source_hash()
+    assert _lib.load().biem_build_id().decode() == _build.source_hash()
+    rep = _build.check_isa()
+    assert sorted(rep) == [64, 128, 192, 256]
+    for kd, r in rep.items():
+        assert r["scratch_bytes"] == 0 and r["vgpr_spills"] == 0 and r["mfma_in_chunk_loop"] == 96, (kd, r)
+        assert set(r["vm"]) <= {"global_load_lds_dwordx4", "global_load_dword", "global_store_dwordx4"}, (kd, r)
+
+
 def test_plane_wave_contract():
     u, g = amd.plane_wave(k=np.asarray(2.0), direction=np.asarray((0.0, 3.0, 0.0)))
     x = np.zeros((3, 4, 2))

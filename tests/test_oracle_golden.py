@@ -185,3 +185,26 @@ def test_translation_block_matrix_is_complex_symmetric_up_to_conjugate_pairing(n
     assert np.abs(P1[deg[:, None] != deg[None, :]]).max() < 1e-9   # inside one degree
     S = G @ np.kron(np.eye(B), P1)
     assert np.abs(S - S.T).max() < 1e-12 * np.abs(S).max()
+
+
+@pytest.mark.parametrize("name", ["a", "ba", "bba"])
+def test_inner_kind_is_the_interior_layer_potential(name):
+    """kind="inner" has no reference fixture (parity unpinned): the oracle's interior expansion is checked against what defines
+    it - the jump of the combined potential across the sphere equals the density (double layer: jump 1, single layer:
+    continuous; i.e. the Wronskian of j_n and h_n), and the value at the centre is the n = 0 term alone."""
+    tr = O.tree(name)
+    d = tr.d
+    k, eta, n_end = 1.7, 0.8, 6
+    e = np.zeros(d); e[0] = 1.0
+    uin, ugr = O.plane_wave(k, e)
+    kw = dict(centers=np.zeros((1, d)), radii=np.array([1.0]), k=k, n_end=n_end, eta=eta, alpha=1.0, beta=0.5, uin=uin, uin_grad=ugr)
+    rin, rout = O.solve_biem(name, kind="inner", **kw), O.solve_biem(name, kind="outer", **kw)
+    xs = np.zeros((2, d)); xs[0, 0] = 1.0; xs[1, 1] = -1.0
+    jump = O.uscat(rout, xs) - O.uscat(rin, xs)
+    want = rin.density.reshape(-1) @ tr.harmonics(xs, n_end)
+    assert np.max(np.abs(jump - want)) < 1e-12 * np.max(np.abs(want))
+    u0 = O.uscat(rin, np.zeros(d))
+    assert np.isfinite(u0)
+    near = O.uscat(rin, 1e-8 * e)                      # the n >= 1 terms vanish like r^n
+    assert abs(u0 - near) < 1e-6 * abs(u0)
+    assert np.isnan(O.uscat(rin, 2.0 * e)) and np.isnan(O.uscat(rout, 0.5 * e))
