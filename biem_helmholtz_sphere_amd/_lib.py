@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libbiem_mi355.so")
 
 BIEM_OK = 0
 TREE_IDS = {"a": 0, "ba": 1, "bba": 2, "caa": 3}
-FILL_REFERENCE, FILL_EQUILIBRATED = 0, 1
+FILL_REFERENCE, FILL_EQUILIBRATED, FILL_SYMMETRIC = 0, 1, 2
 USCAT_FAR_FIELD, USCAT_PER_BALL, USCAT_KIND_INNER, USCAT_POINTS_BATCHED = 1, 2, 4, 8
 
 _vp, _i, _ll, _sz, _dp, _ip = C.c_void_p, C.c_int, C.c_longlong, C.c_size_t, C.c_void_p, C.c_void_p
@@ -30,6 +30,7 @@ SIGNATURES = {
     "biem_plan_destroy": (_i, [_vp]),
     "biem_plan_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_ll)]),
     "biem_plan_labels": (_i, [_vp, _vp, _vp]),
+    "biem_plan_symmetric_order": (_i, [_vp, _vp, _vp]),
     "biem_plan_quadrature": (_i, [_vp, _vp, _vp]),
     "biem_plan_projection": (_i, [_vp, _vp]),
     "biem_plan_terms": (_i, [_vp, _vp, _vp, _vp]),

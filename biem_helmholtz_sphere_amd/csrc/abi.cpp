@@ -89,6 +89,17 @@ int biem_plan_labels(const biem_plan* plan, int* h_labels, int* h_deg) {
   return BIEM_OK;
 }
 
+int biem_plan_symmetric_order(const biem_plan* plan, int* h_partner, int* h_slot) {
+  NEED(plan, "plan");
+  const int U = (int)(plan->units.size() / 2);
+  for (int u = 0; u < U; ++u) {
+    const int h = plan->units[2 * u], p = plan->units[2 * u + 1];
+    if (h_partner) { h_partner[h] = p; h_partner[p] = h; }
+  }
+  if (h_slot) memcpy(h_slot, plan->hpos.data(), plan->hpos.size() * sizeof(int));
+  return BIEM_OK;
+}
+
 int biem_plan_quadrature(const biem_plan* plan, double* h_y, double* h_w) {
   NEED(plan, "plan");
   if (h_y) memcpy(h_y, plan->qy.data(), plan->qy.size() * sizeof(double));
@@ -144,6 +155,8 @@ int biem_fill(const biem_plan* plan, int nb, int B, const double* d_k, const dou
               size_t work_bytes, void* stream) {
   NEED_DEV(plan); NEED(d_k, "d_k"); NEED(d_centers, "d_centers"); NEED(d_tab, "d_tab"); NEED(d_A, "d_A");
   if (B > 1) NEED(d_work, "d_work");
+  if (scaling == BIEM_FILL_SYMMETRIC)
+    return launch_fill_sym(plan, nb, B, d_k, d_centers, geom_batched, d_tab, d_A, lda, sys_stride, n_pad, d_work, work_bytes, (hipStream_t)stream);
   return launch_fill(plan, nb, B, d_k, d_centers, geom_batched, d_tab, scaling, d_A, lda, sys_stride, n_pad, d_work, work_bytes,
                      (hipStream_t)stream);
 }
@@ -270,25 +283,34 @@ static int solve_impl(const biem_plan* plan, int nb, int B, int nrhs, const doub
     const double* cen = d_centers + (geom_batched ? (size_t)s0 * B * d : 0);
     const double* tb = tab + (size_t)s0 * B * 3 * plan->n_end * 2;
     // right-hand side into column n_pad of the augmented matrix (padded rows: zero via fill_pad? -> set explicitly below)
-    rc = launch_fill(plan, c, B, ks, cen, geom_batched, tb, BIEM_FILL_EQUILIBRATED, A, L.lda, L.sys_stride, L.n_pad, T,
-                     fill_workspace_bytes(plan, c, B), st);
+    if (symmetric)
+      rc = launch_fill_sym(plan, c, B, ks, cen, geom_batched, tb, A, L.lda, L.sys_stride, L.n_pad, T, fill_workspace_bytes(plan, c, B), st);
+    else
+      rc = launch_fill(plan, c, B, ks, cen, geom_batched, tb, BIEM_FILL_EQUILIBRATED, A, L.lda, L.sys_stride, L.n_pad, T,
+                       fill_workspace_bytes(plan, c, B), st);
     if (rc) return rc;
     BIEM_HIPCHK(hipMemset2DAsync(A + (size_t)L.n_pad * 2, (size_t)L.lda * 16, 0, (size_t)(L.lda - L.n_pad) * 16,
                                  (size_t)L.n_pad * c, st));
-    rc = launch_rhs_project(plan, c, B, nrhs, d_g + (size_t)s0 * nrhs * B * Q * 2, A + (size_t)L.n_pad * 2, L.sys_stride, L.lda, 1, st);
+    rc = launch_rhs_project(plan, c, B, nrhs, d_g + (size_t)s0 * nrhs * B * Q * 2, A + (size_t)L.n_pad * 2, L.sys_stride, L.lda, 1, st, symmetric);
     if (rc) return rc;
+    bool amax_ready = false;
     if (symmetric) {
-      rc = launch_symmetrize(plan, c, B, nrhs, L.n_pad, tb, A, L.lda, L.sys_stride, false, st);
+      rc = launch_sym_rhs(plan, c, B, nrhs, L.n_pad, tb, A, L.lda, L.sys_stride, false, st);
       if (rc) return rc;
+      // growth check of the factorisation: max |A~| >= 1 (its diagonal is exactly 1), so 1 is a valid, conservative reference
+      // (a system is handed to the pivoted LU when max |U| exceeds 1e3 x this lower bound); saves a pass over the matrix
+      rc = lu_growth_init(Pw, c, L.n_pad, 1.0, st);
+      if (rc) return rc;
+      amax_ready = true;
     }
     rc = launch_lu_factor_solve(c, L.n_pad, nrhs, A, L.lda, L.sys_stride, ipiv, d_info + s0, Pw, lu_workspace_bytes(c, L.n_pad, nrhs), st,
-                                /*keep_multipliers=*/false, symmetric);   // the fused path only needs the solution
+                                /*keep_multipliers=*/false, symmetric, amax_ready);   // the fused path only needs the solution
     if (rc) return rc;
     if (symmetric) {
-      rc = launch_symmetrize(plan, c, B, nrhs, L.n_pad, tb, A, L.lda, L.sys_stride, true, st);
+      rc = launch_sym_rhs(plan, c, B, nrhs, L.n_pad, tb, A, L.lda, L.sys_stride, true, st);
       if (rc) return rc;
     }
-    rc = launch_density(plan, c, B, nrhs, A + (size_t)L.n_pad * 2, L.sys_stride, L.lda, 1, tb, d_density + (size_t)s0 * nrhs * B * H * 2, st);
+    rc = launch_density(plan, c, B, nrhs, A + (size_t)L.n_pad * 2, L.sys_stride, L.lda, 1, tb, d_density + (size_t)s0 * nrhs * B * H * 2, st, symmetric);
     if (rc) return rc;
   }
   return BIEM_OK;

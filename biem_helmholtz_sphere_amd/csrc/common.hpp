@@ -72,14 +72,20 @@ int launch_radial_c(int d, int nmax, int count, const double* d_z, double* d_out
 int launch_harmonics(const biem_plan* p, int count, const double* d_u, double* d_Y, hipStream_t st);
 int launch_ball_tables(const biem_plan* p, int nb, int B, const double* d_k, const double* d_eta, const double* d_radii,
                        int geom_batched, const double* d_alpha, const double* d_beta, int ab_batched, double* d_tab, hipStream_t st);
+// slot_order: harmonic h of a ball goes to / comes from the plan's internal slot hpos[h] (symmetric path) instead of position h
 int launch_rhs_project(const biem_plan* p, int nb, int B, int nrhs, const double* d_g, double* d_f, long long sys_stride,
-                       long long elem_stride, long long rhs_stride, hipStream_t st);
+                       long long elem_stride, long long rhs_stride, hipStream_t st, bool slot_order = false);
 size_t fill_workspace_bytes(const biem_plan* p, int nb, int B);
 int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const double* d_centers, int geom_batched,
                 const double* d_tab, int scaling, double* d_A, long long lda, long long sys_stride, int n_pad,
                 void* d_work, size_t work_bytes, hipStream_t st);
 int launch_density(const biem_plan* p, int nb, int B, int nrhs, const double* d_x, long long sys_stride, long long elem_stride,
-                   long long rhs_stride, const double* d_tab, double* d_density, hipStream_t st);
+                   long long rhs_stride, const double* d_tab, double* d_density, hipStream_t st, bool slot_order = false);
+// the complex-symmetric form A~ = R W^H M W R^-1 in the plan's internal slot order, written only where the L D L^T factorisation
+// reads it (lower triangle + diagonal 64 x 64 tiles); fill_sym_bytes = those bytes per system
+int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const double* d_centers, int geom_batched, const double* d_tab,
+                    double* d_A, long long lda, long long sys_stride, int n_pad, void* d_work, size_t work_bytes, hipStream_t st);
+double fill_sym_bytes(int n_pad);
 int launch_uscat(const biem_plan* p, int nb, int B, int P, const double* d_k, const double* d_eta, const double* d_centers,
                  const double* d_radii, int geom_batched, const double* d_density, const double* d_points, int flags,
                  double* d_out, void* d_work, size_t work_bytes, hipStream_t st);
@@ -90,9 +96,11 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
                            bool symmetric = false, bool amax_ready = false);
 // where the symmetric factorisation keeps max |A|, max |U| per system inside its workspace (unsigned 64-bit patterns of doubles)
 unsigned long long* lu_growth_slots(void* d_work, int nb, int n_pad);
-// [M | F] -> complex-symmetric [R W^H M W R^-1 | R W^H F] in place (inverse_on_solution: x = W R^-1 x~ on the solution columns)
-int launch_symmetrize(const biem_plan* p, int nb, int B, int nrhs, int n_pad, const double* d_tab, double* d_A, long long lda,
-                      long long sys_stride, bool inverse_on_solution, hipStream_t st);
+// preset the slots for a caller that knows (a lower bound of) max |A|: growth[s] = (amax, 0); then pass amax_ready = true
+int lu_growth_init(void* d_work, int nb, int n_pad, double amax, hipStream_t st);
+// right-hand-side columns (slot order): f~ = R W^H f in place; inverse_on_solution: x = W R^-1 x~
+int launch_sym_rhs(const biem_plan* p, int nb, int B, int nrhs, int n_pad, const double* d_tab, double* d_A, long long lda,
+                   long long sys_stride, bool inverse_on_solution, hipStream_t st);
 int launch_lu_solve(int nb, int n_pad, int nrhs, const double* d_LU, long long lda, long long sys_stride, const int* d_ipiv, double* d_B,
                     long long ldb, long long b_stride, hipStream_t st);
 int bench_mfma_f64(int iters, double* tflops, hipStream_t st);

@@ -143,12 +143,14 @@ int launch_ball_tables(const biem_plan* p, int nb, int B, const double* d_k, con
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int H2, double Cd, const int* __restrict__ labels2,
                                                      const int* __restrict__ deg2, int B, const cplx* __restrict__ k,
-                                                     const double* __restrict__ centers, int geom_batched, cplx* __restrict__ T) {
+                                                     const double* __restrict__ centers, int geom_batched, cplx* __restrict__ T,
+                                                     int lower) {
   __shared__ cplx sJ[kMaxRad * 2 + 6];
   __shared__ cplx sH[kMaxRad * 2 + 6];
   int pair = blockIdx.x, s = blockIdx.y;
   int b = pair / B, bp = pair % B;
-  if (b >= bp) return;                       // the fill derives block (bp, b) from (b, bp)
+  // the general fill derives block (bp, b) from (b, bp), b < bp; the symmetric fill forms the LOWER blocks (b > bp) directly
+  if (lower ? b <= bp : b >= bp) return;
   const double* cb = centers + ((geom_batched ? (size_t)s * B : 0) + b) * d;
   const double* cp = centers + ((geom_batched ? (size_t)s * B : 0) + bp) * d;
   double t[4];
@@ -304,7 +306,7 @@ int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const doub
   ProfScope ps(PK_FILL, st, 16.0 * (double)nb * N * (double)N);
   if (B > 1) {
     hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2,
-                       p->d_deg2, B, (const cplx*)d_k, d_centers, geom_batched, T);
+                       p->d_deg2, B, (const cplx*)d_k, d_centers, geom_batched, T, 0);
     BIEM_LAUNCHCHK();
   }
   size_t shm = (size_t)(p->H2 + 2 * H) * sizeof(cplx) + (size_t)p->chunk_terms_max * 10 + (size_t)(p->chunk_ents_max + 1) * 4 + 16;
@@ -326,13 +328,214 @@ int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const doub
 }
 
 // ---------------------------------------------------------------------------------------------
+// Symmetric fill (default path): the complex-symmetric form A~ = R W^H M W R^-1 of the equilibrated system, written ONCE and
+// only where the L D L^T factorisation reads it (lower triangle + the diagonal 64 x 64 tiles) - the general fill followed by
+// the in-place symmetrising transform moved 4x the bytes.
+//   W: unitary map to real harmonics (units (h, p), conj Y_h = Y_p: "cosine" (e_h + e_p)/sqrt2, "sine" i (e_p - e_h)/sqrt2),
+//   R = diag(1/sqrt(gj gh)) per (ball, degree).  With q_b[n] = gj / sqrt(gj gh) the block (b, b'), b != b', is
+//        A~[(b,x), (b',x')] = q_b[n] q_b'[n'] (W^H S_{bb'} W)[x, x'],      S = (S|R)^T raw sums,  diagonal blocks = identity.
+// Internal order of a ball's unknowns: slot u = cosine combination of unit u, slot U + spos[u] = its sine combination
+// (plan.hpp); consecutive lanes own consecutive u', so every store instruction covers contiguous runs of a matrix row.
+// One 512-thread workgroup owns a chunk of unit pairs (its four term lists per pair stay in LDS) and loops over
+// (lower ball pair, system) combinations: per combination only the pair table T (H2 complex) is staged - fetched into
+// registers during the previous combination's contraction - so the term lists are read from L2 once per workgroup.
+// Each thread runs the four independent chains of its 2 x 2 block (the per-term chain idx -> T -> fma is LDS-latency bound).
+// ---------------------------------------------------------------------------------------------
+constexpr int FILL_SYM_THREADS = 512;
+constexpr int FILL_SYM_MAXT = 14;          // pair-table elements prefetched per thread: H2 <= 14 * 512
+
+// KT = pair-table elements each thread carries in registers from one combination to the next (KT * 512 >= H2); the loads are
+// unconditional with a clamped index (a conditionally assigned register array was kept in scratch by hipcc)
+template <int KT>
+__global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_sym(int H, int U, int H2, int n_end, int B, int nb, int npairs,
+                                                                const int* __restrict__ deg, const int* __restrict__ units,
+                                                                const int* __restrict__ spos, const int* __restrict__ qchunk,
+                                                                int terms_max, int pairs_max, const uint32_t* __restrict__ qptr,
+                                                                const double* __restrict__ qcoef, const uint16_t* __restrict__ qidx,
+                                                                const cplx* __restrict__ T, const cplx* __restrict__ tab,
+                                                                cplx* __restrict__ A, long long lda, long long sys_stride) {
+  extern __shared__ char smem[];
+  cplx* sT = (cplx*)smem;                                  // [H2] pair table of the current combination
+  cplx* sQ = sT + H2;                                      // [2][n_end]: q of the row ball, q of the column ball
+  double* sCoef = (double*)(sQ + 2 * n_end);               // [terms_max + 1]: the chunk's terms, then a dummy (0.0, index 0)
+  uint32_t* sPtr = (uint32_t*)(sCoef + terms_max + 1);     // [4 pairs_max + 1], relative to the chunk's first term
+  uint16_t* sIdx = (uint16_t*)(sPtr + 4 * pairs_max + 1);  // [terms_max + 1]
+  const int tid = threadIdx.x;
+  const int p0 = qchunk[blockIdx.x], p1 = qchunk[blockIdx.x + 1], npr = p1 - p0;
+  const uint32_t t0 = qptr[4 * (size_t)p0], t1 = qptr[4 * (size_t)p1];
+  for (uint32_t q = t0 + tid; q < t1; q += FILL_SYM_THREADS) { sCoef[q - t0] = qcoef[q]; sIdx[q - t0] = qidx[q]; }
+  for (int e = tid; e <= 4 * npr; e += FILL_SYM_THREADS) sPtr[e] = qptr[4 * (size_t)p0 + e] - t0;
+  if (tid == 0) { sCoef[t1 - t0] = 0.0; sIdx[t1 - t0] = 0; }
+  // this thread's unit pair (fixed for the whole kernel)
+  const bool active = tid < npr;
+  const int pi = p0 + (active ? tid : 0);
+  const int u = pi / U, v = pi - u * U;
+  const int rh = units[2 * u], rp = units[2 * u + 1], ch = units[2 * v], cp = units[2 * v + 1];
+  const bool r2 = rp != rh, c2 = cp != ch;                 // two rows / two columns in this block
+  const int row_c = u, row_s = r2 ? U + spos[u] : 0, col_c = v, col_s = c2 ? U + spos[v] : 0;
+  const int nrow = deg[rh], ncol = deg[ch];
+  const double q2 = 0.70710678118654752440;
+  const int ncomb = npairs * nb;
+  // fourteen named registers instead of an array: hipcc kept every array form (plain, unrolled, compile-time indexed through
+  // lambdas) in scratch memory
+#define BIEM_TN_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
+#define BIEM_TN_DECL(k) cplx tn##k = make_double2(0.0, 0.0);
+  BIEM_TN_LIST(BIEM_TN_DECL)
+#define BIEM_TN_LOAD(k) if (k < KT) { const int l = k * FILL_SYM_THREADS + tid; tn##k = Tp_[l < H2 ? l : H2 - 1]; }
+#define BIEM_TN_PUT(k) if (k < KT) { const int l = k * FILL_SYM_THREADS + tid; if (l < H2) sT[l] = tn##k; }
+  auto pair_of = [&](int pr, int& b, int& bp) {           // pr-th lower pair (b > bp), row-major over b
+    int bb = (int)((sqrtf(8.0f * (float)pr + 1.0f) + 1.0f) * 0.5f);
+    while (bb * (bb - 1) / 2 > pr) --bb;
+    while ((bb + 1) * bb / 2 <= pr) ++bb;
+    b = bb; bp = pr - bb * (bb - 1) / 2;
+  };
+  auto table_of = [&](int cb) -> const cplx* {
+    const int s = cb / npairs, pr = cb - s * npairs;
+    int b, bp; pair_of(pr, b, bp);
+    return T + ((size_t)s * B * B + (size_t)b * B + bp) * H2;
+  };
+  int comb = blockIdx.y;
+  if (comb < ncomb) { const cplx* Tp_ = table_of(comb); BIEM_TN_LIST(BIEM_TN_LOAD) }
+  for (; comb < ncomb; comb += gridDim.y) {
+    const int s = comb / npairs, pr = comb - s * npairs;
+    int b, bp; pair_of(pr, b, bp);
+    __syncthreads();                                       // the previous combination's readers are done (also orders the chunk loads)
+    BIEM_TN_LIST(BIEM_TN_PUT)
+    if (tid < 2 * n_end) {
+      const int which = tid >= n_end, n = tid - which * n_end;
+      const cplx* tb = tab + ((size_t)s * B + (which ? bp : b)) * 3 * n_end;
+      sQ[tid] = cmul(tb[n], crecip(zsqrt(cmul(tb[n], tb[n_end + n]))));     // gj / sqrt(gj gh)
+    }
+    __syncthreads();
+    if (comb + (int)gridDim.y < ncomb) { const cplx* Tp_ = table_of(comb + (int)gridDim.y); BIEM_TN_LIST(BIEM_TN_LOAD) }   // lands while this combination is contracted
+    if (!active) continue;
+    // the four chains of the 2 x 2 block advance together: per step all coefficient / index reads are issued, then the four
+    // table reads, then the FMAs (with one `if (i < len)` block per chain hipcc waited for every chain's LDS reads in turn:
+    // 70 % of the wave cycles were waits).  A chain that has run out reads the chunk's dummy term (coefficient 0, index 0).
+    const uint32_t dummy = sPtr[4 * npr];                 // = number of terms of the chunk: the slot behind them
+    uint32_t q0 = sPtr[4 * tid], q1 = sPtr[4 * tid + 1], q2p = sPtr[4 * tid + 2], q3 = sPtr[4 * tid + 3];
+    const uint32_t e0 = q1, e1 = q2p, e2 = q3, e3 = sPtr[4 * tid + 4];
+    uint32_t lm = e0 - q0;
+    lm = (e1 - q1) > lm ? (e1 - q1) : lm; lm = (e2 - q2p) > lm ? (e2 - q2p) : lm; lm = (e3 - q3) > lm ? (e3 - q3) : lm;
+    double s0r = 0, s0i = 0, s1r = 0, s1i = 0, s2r = 0, s2i = 0, s3r = 0, s3i = 0;
+    for (uint32_t i = 0; i < lm; ++i) {
+      const uint32_t g0 = q0 < e0 ? q0 : dummy, g1 = q1 < e1 ? q1 : dummy, g2 = q2p < e2 ? q2p : dummy, g3 = q3 < e3 ? q3 : dummy;
+      const double c0 = sCoef[g0], c1 = sCoef[g1], c2v = sCoef[g2], c3 = sCoef[g3];
+      const unsigned i0 = sIdx[g0], i1 = sIdx[g1], i2 = sIdx[g2], i3 = sIdx[g3];
+      const cplx z0 = sT[i0], z1 = sT[i1], z2 = sT[i2], z3 = sT[i3];
+      s0r = fma(c0, z0.x, s0r); s0i = fma(c0, z0.y, s0i);
+      s1r = fma(c1, z1.x, s1r); s1i = fma(c1, z1.y, s1i);
+      s2r = fma(c2v, z2.x, s2r); s2i = fma(c2v, z2.y, s2i);
+      s3r = fma(c3, z3.x, s3r); s3i = fma(c3, z3.y, s3i);
+      ++q0; ++q1; ++q2p; ++q3;
+    }
+    // W^H S W on the 2 x 2 block: rows (h + p)/sqrt2, i (h - p)/sqrt2; columns (h' + p')/sqrt2, i (p' - h')/sqrt2
+    cplx x00 = make_double2(s0r, s0i), x01 = make_double2(s1r, s1i), x10 = make_double2(s2r, s2i), x11 = make_double2(s3r, s3i);
+    if (r2) {
+      const cplx a0c = make_double2((x00.x + x10.x) * q2, (x00.y + x10.y) * q2), a1c = make_double2((x01.x + x11.x) * q2, (x01.y + x11.y) * q2);
+      const cplx d0 = make_double2((x00.x - x10.x) * q2, (x00.y - x10.y) * q2), d1 = make_double2((x01.x - x11.x) * q2, (x01.y - x11.y) * q2);
+      x00 = a0c; x01 = a1c; x10 = make_double2(-d0.y, d0.x); x11 = make_double2(-d1.y, d1.x);
+    }
+    if (c2) {
+      const cplx a0c = make_double2((x00.x + x01.x) * q2, (x00.y + x01.y) * q2), d0 = make_double2((x01.x - x00.x) * q2, (x01.y - x00.y) * q2);
+      const cplx a1c = make_double2((x10.x + x11.x) * q2, (x10.y + x11.y) * q2), d1 = make_double2((x11.x - x10.x) * q2, (x11.y - x10.y) * q2);
+      x00 = a0c; x01 = make_double2(-d0.y, d0.x); x10 = a1c; x11 = make_double2(-d1.y, d1.x);
+    }
+    const cplx scale = cmul(sQ[nrow], sQ[n_end + ncol]);
+    cplx* As = A + (size_t)s * sys_stride;
+    auto put = [&](int rslot, int cslot, cplx val) {
+      const int row = b * H + rslot, col = bp * H + cslot;   // b > bp: strictly below the diagonal
+      const cplx w = cmul(val, scale);
+      As[(size_t)row * lda + col] = w;
+      if ((row >> 6) == (col >> 6)) As[(size_t)col * lda + row] = w;     // a diagonal 64 x 64 tile is read whole: mirror (A~ = A~^T)
+    };
+    put(row_c, col_c, x00);
+    if (c2) put(row_c, col_s, x01);
+    if (r2) { put(row_s, col_c, x10); if (c2) put(row_s, col_s, x11); }
+  }
+#undef BIEM_TN_LIST
+#undef BIEM_TN_DECL
+#undef BIEM_TN_LOAD
+#undef BIEM_TN_PUT
+}
+
+// what k_fill_sym leaves: the identity diagonal blocks and the padding, again only where the factorisation reads
+// (columns c < 64 (r / 64 + 1) of row r); one workgroup per row
+__global__ void __launch_bounds__(64) k_fill_sym_diag(int H, int N, int n_pad, cplx* __restrict__ A, long long lda, long long sys_stride) {
+  const int r = blockIdx.x, s = blockIdx.y;
+  cplx* row = A + (size_t)s * sys_stride + (size_t)r * lda;
+  const int cend = (r / 64 + 1) * 64;
+  const int br = r / H;
+  for (int c = threadIdx.x; c < cend; c += 64)
+    if (r >= N || c >= N || c / H == br) row[c] = (r == c) ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
+}
+
+// bytes of one system the symmetric path writes and the factorisation reads: sum over rows of 16 * 64 (r / 64 + 1)
+double fill_sym_bytes(int n_pad) {
+  const double t = n_pad / 64;
+  return 16.0 * 64.0 * 64.0 * t * (t + 1.0) * 0.5;
+}
+
+int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const double* d_centers, int geom_batched, const double* d_tab,
+                    double* d_A, long long lda, long long sys_stride, int n_pad, void* d_work, size_t work_bytes, hipStream_t st) {
+  const int H = p->H, N = B * H, U = (int)(p->units.size() / 2);
+  if (nb <= 0 || B <= 0) return BIEM_OK;
+  if (lda < n_pad || n_pad < N || n_pad % 64) { set_error("biem_fill (symmetric): lda / n_pad too small or n_pad not a multiple of 64"); return BIEM_ERR_ARG; }
+  if (work_bytes < fill_workspace_bytes(p, nb, B)) { set_error("biem_fill: workspace too small"); return BIEM_ERR_ARG; }
+  if (2 * p->n_end > kMaxRad) { set_error("n_end=%d exceeds the built table size", p->n_end); return BIEM_ERR_UNSUPPORTED; }
+  if (nb > 65535) { set_error("biem_fill (symmetric): at most 65535 systems per call"); return BIEM_ERR_ARG; }
+  cplx* T = (cplx*)d_work;
+  ProfScope ps(PK_FILL, st, (double)nb * fill_sym_bytes(n_pad));
+  if (B > 1) {
+    const int nchunks = (int)p->qchunk.size() - 1;
+    const size_t shm = (size_t)(p->H2 + 2 * p->n_end) * sizeof(cplx) + (size_t)(p->qchunk_terms_max + 1) * 10 + (size_t)(4 * p->qchunk_pairs_max + 1) * 4 + 16;
+    if (nchunks <= 0 || shm > 160 * 1024 || p->H2 > FILL_SYM_MAXT * FILL_SYM_THREADS) {
+      set_error("biem_fill (symmetric): tables do not fit LDS (n_end=%d: H2=%d, chunk terms=%d)", p->n_end, p->H2, p->qchunk_terms_max);
+      return BIEM_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2, p->d_deg2, B,
+                       (const cplx*)d_k, d_centers, geom_batched, T, 1);
+    BIEM_LAUNCHCHK();
+
+    const int npairs = B * (B - 1) / 2;
+    const long long ncomb = (long long)npairs * nb;
+    // enough workgroups to fill the chip a few times over, each with a long loop over combinations
+    long long gy = (8 * 256 + nchunks - 1) / nchunks;
+    if (gy < 1) gy = 1;
+    if (gy > ncomb) gy = ncomb;
+    if (gy > 65535) gy = 65535;
+    const int kt_need = (p->H2 + FILL_SYM_THREADS - 1) / FILL_SYM_THREADS;
+#define BIEM_LAUNCH_FILL_SYM(KT)                                                                                                          \
+  {                                                                                                                                       \
+    BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_fill_sym<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                  \
+    hipLaunchKernelGGL(k_fill_sym<KT>, dim3(nchunks, (unsigned)gy), dim3(FILL_SYM_THREADS), shm, st, H, U, p->H2, p->n_end, B, nb, npairs, \
+                       p->d_deg, p->d_units, p->d_spos, p->d_qchunk, p->qchunk_terms_max, p->qchunk_pairs_max, p->d_qptr, p->d_qcoef,     \
+                       p->d_qidx16, T, (const cplx*)d_tab, (cplx*)d_A, lda, sys_stride);                                                  \
+  }
+    if (kt_need <= 1) BIEM_LAUNCH_FILL_SYM(1)
+    else if (kt_need <= 2) BIEM_LAUNCH_FILL_SYM(2)
+    else if (kt_need <= 3) BIEM_LAUNCH_FILL_SYM(3)
+    else if (kt_need <= 4) BIEM_LAUNCH_FILL_SYM(4)
+    else if (kt_need <= 6) BIEM_LAUNCH_FILL_SYM(6)
+    else if (kt_need <= 8) BIEM_LAUNCH_FILL_SYM(8)
+    else if (kt_need <= 11) BIEM_LAUNCH_FILL_SYM(11)
+    else BIEM_LAUNCH_FILL_SYM(14)
+#undef BIEM_LAUNCH_FILL_SYM
+    BIEM_LAUNCHCHK();
+  }
+  hipLaunchKernelGGL(k_fill_sym_diag, dim3(n_pad, nb), dim3(64), 0, st, H, N, n_pad, (cplx*)d_A, lda, sys_stride);
+  BIEM_LAUNCHCHK();
+  return BIEM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // RHS projection  f[row][h] = sum_q g[row][q] W[q][h]   (ush.expand, _biem.py:627-639)
 // block = RT rows x 256 columns; g rows staged in LDS, W streamed coalesced along h.
 // ---------------------------------------------------------------------------------------------
 template <int RT>
 __global__ void __launch_bounds__(256) k_rhs_project(int H, int Q, int rows, int B, int nrhs, const cplx* __restrict__ g,
                                                       const cplx* __restrict__ W, cplx* __restrict__ f, long long sys_stride,
-                                                      long long elem_stride, long long rhs_stride) {
+                                                      long long elem_stride, long long rhs_stride, const int* __restrict__ hpos) {
   extern __shared__ cplx sg[];   // [RT][QC]
   constexpr int QC = 256;
   int row0 = blockIdx.y * RT;
@@ -360,13 +563,13 @@ __global__ void __launch_bounds__(256) k_rhs_project(int H, int Q, int rows, int
       int row = row0 + r;
       if (row >= rows) break;
       long long b = row % B, sr = row / B, rr = sr % nrhs, s = sr / nrhs;     // row = (s*nrhs + rr)*B + b
-      f[(size_t)s * sys_stride + ((size_t)b * H + h) * elem_stride + (size_t)rr * rhs_stride] = acc[r];
+      f[(size_t)s * sys_stride + ((size_t)b * H + (hpos ? hpos[h] : h)) * elem_stride + (size_t)rr * rhs_stride] = acc[r];
     }
   }
 }
 
 int launch_rhs_project(const biem_plan* p, int nb, int B, int nrhs, const double* d_g, double* d_f, long long sys_stride,
-                       long long elem_stride, long long rhs_stride, hipStream_t st) {
+                       long long elem_stride, long long rhs_stride, hipStream_t st, bool slot_order) {
   if (nrhs < 1) { set_error("biem_rhs_project: nrhs < 1"); return BIEM_ERR_ARG; }
   int rows = nb * nrhs * B;
   if (rows <= 0) return BIEM_OK;
@@ -374,102 +577,61 @@ int launch_rhs_project(const biem_plan* p, int nb, int B, int nrhs, const double
   size_t shm = (size_t)RT * 256 * sizeof(cplx);
   ProfScope ps(PK_RHS, st, 8.0 * (double)rows * p->Q * p->H);
   hipLaunchKernelGGL(k_rhs_project<RT>, dim3((p->H + 255) / 256, (rows + RT - 1) / RT), dim3(256), shm, st, p->H, p->Q, rows, B,
-                     nrhs, (const cplx*)d_g, (const cplx*)p->d_W, (cplx*)d_f, sys_stride, elem_stride, rhs_stride);
+                     nrhs, (const cplx*)d_g, (const cplx*)p->d_W, (cplx*)d_f, sys_stride, elem_stride, rhs_stride,
+                     slot_order ? p->d_hpos : nullptr);
   BIEM_LAUNCHCHK();
   return BIEM_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-// complex-symmetric form of the equilibrated system (for the L D L^T path).
-// With W the unitary map to real harmonics (pairs h <= p, conj Y_h = Y_p:  W e_h = (e_h + e_p)/sqrt2,  W e_p = i (e_p - e_h)/sqrt2)
-// and R = diag(1 / sqrt(gj gh)) per (ball, degree),   A~ = R W^H M W R^{-1}   is complex symmetric  (G P symmetric, see
-// tests/test_oracle_golden.py::test_translation_block_matrix_is_complex_symmetric_up_to_conjugate_pairing), f~ = R W^H f,
-// and the solution of the original system is x = W R^{-1} x~.
-// k_symmetrize: one thread per (row unit, column unit) 2 x 2 block of [M | F], in place; right-hand-side columns take the row
-// transform only.  k_unsymmetrize: x from x~ in the right-hand-side columns.
+// right-hand sides / solutions of the complex-symmetric form (the matrix itself comes from k_fill_sym above):
+//   f~ = R W^H f  before the factorisation,   x = W R^-1 x~  after it,   R = diag(1 / sqrt(gj gh)) per (ball, degree).
+// The right-hand-side columns hold a ball's harmonics in the internal slot order (biem_rhs_project with the plan's hpos: h of
+// unit u in slot u, its partner p in slot U + spos[u]), so both transforms work in place on the two slots of a unit.
 // ---------------------------------------------------------------------------------------------
 __device__ inline cplx sym_r(const cplx* __restrict__ tball, int n_end, int n) {   // 1 / sqrt(gj gh)
   return crecip(zsqrt(cmul(tball[n], tball[n_end + n])));
 }
 
-__global__ void __launch_bounds__(256) k_symmetrize(int H, int U, int n_end, int B, int nrhs, int n_pad, const int* __restrict__ units,
-                                                     const int* __restrict__ deg, const cplx* __restrict__ tab, cplx* __restrict__ A,
-                                                     long long lda, long long sys_stride) {
-  const int s = blockIdx.z;
-  const int cu = blockIdx.x * 256 + threadIdx.x;                // column unit over all balls, then the right-hand sides
-  if (cu >= B * U + nrhs) return;
-  for (int ru = blockIdx.y; ru < B * U; ru += gridDim.y) {      // row unit over all balls (grid.y is capped at 65535)
-    const int br = ru / U, ur = ru - br * U;
-    const int rh = units[2 * ur], rp = units[2 * ur + 1];
-    const cplx* ts = tab + (size_t)s * B * 3 * n_end;
-    const cplx rr = sym_r(ts + (size_t)br * 3 * n_end, n_end, deg[rh]);
-    cplx* As = A + (size_t)s * sys_stride;
-    cplx* row_h = As + (size_t)(br * H + rh) * lda;
-    cplx* row_p = As + (size_t)(br * H + rp) * lda;
-    const double q2 = 0.70710678118654752440;
-    int ch, cp; cplx scale;
-    if (cu < B * U) {
-      const int bc = cu / U, uc = cu - bc * U;
-      ch = bc * H + units[2 * uc]; cp = bc * H + units[2 * uc + 1];
-      scale = cmul(rr, zsqrt(cmul(ts[(size_t)bc * 3 * n_end + deg[units[2 * uc]]], ts[(size_t)bc * 3 * n_end + n_end + deg[units[2 * uc]]])));   // r_row / r_col
-    } else { ch = cp = n_pad + (cu - B * U); scale = rr; }
-    // the L D L^T factorisation reads only the lower triangle and the diagonal 64 x 64 blocks: blocks wholly right of their
-    // rows' diagonal blocks are neither transformed nor written (their memory keeps the untransformed M; never read)
-    if (cu < B * U && (ch < cp ? ch : cp) >= ((br * H + (rh > rp ? rh : rp)) / 64 + 1) * 64) continue;
-    cplx x00 = row_h[ch], x01 = row_h[cp], x10 = x00, x11 = x01;
-    if (rp != rh) { x10 = row_p[ch]; x11 = row_p[cp]; }
-    if (rp != rh) {   // rows: (h + p)/sqrt2, i (h - p)/sqrt2
-      cplx a0 = make_double2((x00.x + x10.x) * q2, (x00.y + x10.y) * q2), a1 = make_double2((x01.x + x11.x) * q2, (x01.y + x11.y) * q2);
-      cplx d0 = make_double2((x00.x - x10.x) * q2, (x00.y - x10.y) * q2), d1 = make_double2((x01.x - x11.x) * q2, (x01.y - x11.y) * q2);
-      x00 = a0; x01 = a1; x10 = make_double2(-d0.y, d0.x); x11 = make_double2(-d1.y, d1.x);
-    }
-    if (cp != ch) {   // columns: (h + p)/sqrt2, i (p - h)/sqrt2
-      cplx a0 = make_double2((x00.x + x01.x) * q2, (x00.y + x01.y) * q2), d0 = make_double2((x01.x - x00.x) * q2, (x01.y - x00.y) * q2);
-      cplx a1 = make_double2((x10.x + x11.x) * q2, (x10.y + x11.y) * q2), d1 = make_double2((x11.x - x10.x) * q2, (x11.y - x10.y) * q2);
-      x00 = a0; x01 = make_double2(-d0.y, d0.x); x10 = a1; x11 = make_double2(-d1.y, d1.x);
-    }
-    row_h[ch] = cmul(x00, scale);
-    if (cp != ch) row_h[cp] = cmul(x01, scale);
-    if (rp != rh) {
-      row_p[ch] = cmul(x10, scale);
-      if (cp != ch) row_p[cp] = cmul(x11, scale);
-    }
-  }
-}
-
-__global__ void __launch_bounds__(256) k_unsymmetrize(int H, int U, int n_end, int B, int nrhs, int n_pad, const int* __restrict__ units,
-                                                       const int* __restrict__ deg, const cplx* __restrict__ tab, cplx* __restrict__ A,
-                                                       long long lda, long long sys_stride) {
+__global__ void __launch_bounds__(256) k_sym_rhs(int H, int U, int n_end, int B, int nrhs, int n_pad, const int* __restrict__ units,
+                                                  const int* __restrict__ spos, const int* __restrict__ deg, const cplx* __restrict__ tab,
+                                                  cplx* __restrict__ A, long long lda, long long sys_stride, int inverse) {
   const int s = blockIdx.y;
-  const int t = blockIdx.x * 256 + threadIdx.x;                 // (row unit over all balls, rhs)
+  const int t = blockIdx.x * 256 + threadIdx.x;                 // (unit over all balls, rhs)
   if (t >= B * U * nrhs) return;
   const int q = t % nrhs, ru = t / nrhs, br = ru / U, ur = ru - br * U;
   const int rh = units[2 * ur], rp = units[2 * ur + 1];
-  const cplx* ts = tab + (size_t)s * B * 3 * n_end + (size_t)br * 3 * n_end;
-  const cplx g = zsqrt(cmul(ts[deg[rh]], ts[n_end + deg[rh]]));      // 1 / r
-  cplx* As = A + (size_t)s * sys_stride + n_pad + q;
-  cplx* ph = As + (size_t)(br * H + rh) * lda;
-  cplx* pp = As + (size_t)(br * H + rp) * lda;
-  const cplx yh = cmul(*ph, g);
-  if (rp == rh) { *ph = yh; return; }
-  const cplx yp = cmul(*pp, g);
-  const double q2 = 0.70710678118654752440;                            // x_h = (y_h - i y_p)/sqrt2, x_p = (y_h + i y_p)/sqrt2
-  *ph = make_double2((yh.x + yp.y) * q2, (yh.y - yp.x) * q2);
-  *pp = make_double2((yh.x - yp.y) * q2, (yh.y + yp.x) * q2);
+  const cplx* ts = tab + ((size_t)s * B + br) * 3 * n_end;
+  cplx* F = A + (size_t)s * sys_stride + n_pad + q;
+  cplx* pc = F + (size_t)(br * H + ur) * lda;
+  cplx* psn = F + (size_t)(br * H + U + (rp != rh ? spos[ur] : 0)) * lda;
+  const double q2 = 0.70710678118654752440;
+  if (!inverse) {
+    const cplx r = sym_r(ts, n_end, deg[rh]);
+    const cplx fh = *pc;
+    if (rp == rh) { *pc = cmul(fh, r); return; }
+    const cplx fp = *psn;
+    const cplx a = make_double2((fh.x + fp.x) * q2, (fh.y + fp.y) * q2), d = make_double2((fh.x - fp.x) * q2, (fh.y - fp.y) * q2);
+    *pc = cmul(a, r);
+    *psn = cmul(make_double2(-d.y, d.x), r);                    // i (f_h - f_p) / sqrt2
+  } else {
+    const cplx g = zsqrt(cmul(ts[deg[rh]], ts[n_end + deg[rh]]));      // 1 / r
+    const cplx yh = cmul(*pc, g);
+    if (rp == rh) { *pc = yh; return; }
+    const cplx yp = cmul(*psn, g);                              // x_h = (y_c - i y_s)/sqrt2, x_p = (y_c + i y_s)/sqrt2
+    *pc = make_double2((yh.x + yp.y) * q2, (yh.y - yp.x) * q2);
+    *psn = make_double2((yh.x - yp.y) * q2, (yh.y + yp.x) * q2);
+  }
 }
 
-int launch_symmetrize(const biem_plan* p, int nb, int B, int nrhs, int n_pad, const double* d_tab, double* d_A, long long lda,
-                      long long sys_stride, bool inverse_on_solution, hipStream_t st) {
+int launch_sym_rhs(const biem_plan* p, int nb, int B, int nrhs, int n_pad, const double* d_tab, double* d_A, long long lda,
+                   long long sys_stride, bool inverse_on_solution, hipStream_t st) {
   const int U = (int)(p->units.size() / 2);
-  if (nb <= 0 || B <= 0) return BIEM_OK;
+  if (nb <= 0 || B <= 0 || nrhs <= 0) return BIEM_OK;
   if (nb > 65535) { set_error("biem symmetric path: at most 65535 systems per call"); return BIEM_ERR_ARG; }
-  ProfScope ps(PK_SWAP, st, 0.0);   // class 4: row interchanges in the LU, this transform in the symmetric path
-  if (!inverse_on_solution)
-    hipLaunchKernelGGL(k_symmetrize, dim3((B * U + nrhs + 255) / 256, B * U < 65535 ? B * U : 65535, nb), dim3(256), 0, st, p->H, U, p->n_end, B, nrhs, n_pad,
-                       p->d_units, p->d_deg, (const cplx*)d_tab, (cplx*)d_A, lda, sys_stride);
-  else
-    hipLaunchKernelGGL(k_unsymmetrize, dim3((B * U * nrhs + 255) / 256, nb), dim3(256), 0, st, p->H, U, p->n_end, B, nrhs, n_pad,
-                       p->d_units, p->d_deg, (const cplx*)d_tab, (cplx*)d_A, lda, sys_stride);
+  ProfScope ps(PK_SWAP, st, 0.0);   // class 4: row interchanges in the LU, these transforms in the symmetric path
+  hipLaunchKernelGGL(k_sym_rhs, dim3((B * U * nrhs + 255) / 256, nb), dim3(256), 0, st, p->H, U, p->n_end, B, nrhs, n_pad, p->d_units,
+                     p->d_spos, p->d_deg, (const cplx*)d_tab, (cplx*)d_A, lda, sys_stride, inverse_on_solution ? 1 : 0);
   BIEM_LAUNCHCHK();
   return BIEM_OK;
 }
@@ -479,7 +641,7 @@ int launch_symmetrize(const biem_plan* p, int nb, int B, int nrhs, int n_pad, co
 // ---------------------------------------------------------------------------------------------
 __global__ void k_density(int H, int n_end, int B, int nrhs, long long total, const int* __restrict__ deg, const cplx* __restrict__ x,
                           long long sys_stride, long long elem_stride, long long rhs_stride, const cplx* __restrict__ tab,
-                          cplx* __restrict__ dens) {
+                          cplx* __restrict__ dens, const int* __restrict__ hpos) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // i = ((s*nrhs + r)*B + b)*H + h
   if (i >= total) return;
   int h = (int)(i % H);
@@ -487,17 +649,17 @@ __global__ void k_density(int H, int n_end, int B, int nrhs, long long total, co
   long long b = srb % B, sr = srb / B, r = sr % nrhs, s = sr / nrhs;
   int n = deg[h];
   const cplx* t = tab + (size_t)(s * B + b) * 3 * n_end;
-  cplx v = x[(size_t)s * sys_stride + ((size_t)b * H + h) * elem_stride + (size_t)r * rhs_stride];
+  cplx v = x[(size_t)s * sys_stride + ((size_t)b * H + (hpos ? hpos[h] : h)) * elem_stride + (size_t)r * rhs_stride];
   dens[i] = cmul(v, crecip(cmul(t[n_end + n], t[2 * n_end + n])));
 }
 
 int launch_density(const biem_plan* p, int nb, int B, int nrhs, const double* d_x, long long sys_stride, long long elem_stride,
-                   long long rhs_stride, const double* d_tab, double* d_density, hipStream_t st) {
+                   long long rhs_stride, const double* d_tab, double* d_density, hipStream_t st, bool slot_order) {
   if (nrhs < 1) { set_error("biem_density: nrhs < 1"); return BIEM_ERR_ARG; }
   long long total = (long long)nb * nrhs * B * p->H;
   if (total <= 0) return BIEM_OK;
   hipLaunchKernelGGL(k_density, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p->H, p->n_end, B, nrhs, total, p->d_deg,
-                     (const cplx*)d_x, sys_stride, elem_stride, rhs_stride, (const cplx*)d_tab, (cplx*)d_density);
+                     (const cplx*)d_x, sys_stride, elem_stride, rhs_stride, (const cplx*)d_tab, (cplx*)d_density, slot_order ? p->d_hpos : nullptr);
   BIEM_LAUNCHCHK();
   return BIEM_OK;
 }

@@ -77,6 +77,18 @@ unsigned long long* lu_growth_slots(void* d_work, int nb, int n_pad) {
   int* tri = (int*)(Winv + (size_t)nb * NB * NB);
   return (unsigned long long*)(tri + ((T * (T + 1) / 2 + 63) / 64) * 64);
 }
+__global__ void k_growth_preset(int nb, unsigned long long* __restrict__ growth, double amax) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nb) return;
+  growth[2 * s] = (unsigned long long)__double_as_longlong(amax);
+  growth[2 * s + 1] = 0ULL;
+}
+int lu_growth_init(void* d_work, int nb, int n_pad, double amax, hipStream_t st) {
+  if (nb <= 0) return BIEM_OK;
+  hipLaunchKernelGGL(k_growth_preset, dim3((nb + 63) / 64), dim3(64), 0, st, nb, lu_growth_slots(d_work, nb, n_pad), amax);
+  BIEM_LAUNCHCHK();
+  return BIEM_OK;
+}
 __global__ void k_growth_check(int nb, int n_pad, const unsigned long long* __restrict__ growth, int* __restrict__ info, double limit) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nb) return;

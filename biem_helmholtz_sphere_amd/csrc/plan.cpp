@@ -294,6 +294,53 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
       e0 = e1;
     }
   }
+  // ---- unit-pair ("quad") term lists and chunks of the symmetric fill ----
+  {
+    const int U = (int)(p->units.size() / 2);
+    p->spos.assign(U, -1); p->hpos.assign(H, 0);
+    int ns = 0;
+    for (int u = 0; u < U; ++u) {
+      const int h = p->units[2 * u], pp = p->units[2 * u + 1];
+      p->hpos[h] = u;
+      if (pp != h) { p->spos[u] = ns; p->hpos[pp] = U + ns; ++ns; }
+    }
+    p->qptr.assign((size_t)4 * U * U + 1, 0);
+    p->qcoef.clear(); p->qidx16.clear();
+    p->qcoef.reserve(p->coef.size()); p->qidx16.reserve(p->coef.size());
+    for (int u = 0; u < U; ++u)
+      for (int v = 0; v < U; ++v) {
+        const int hh[2] = {p->units[2 * u], p->units[2 * u + 1]}, cc[2] = {p->units[2 * v], p->units[2 * v + 1]};
+        for (int slot = 0; slot < 4; ++slot) {
+          const int ri = slot >> 1, ci = slot & 1;
+          const bool present = (ri == 0 || hh[1] != hh[0]) && (ci == 0 || cc[1] != cc[0]);
+          if (present) {
+            const size_t e = (size_t)hh[ri] * H + cc[ci];
+            for (uint32_t q = p->ptr[e]; q < p->ptr[e + 1]; ++q) { p->qcoef.push_back(p->coef[q]); p->qidx16.push_back((uint16_t)p->tidx[q]); }
+          }
+          p->qptr[((size_t)u * U + v) * 4 + slot + 1] = (uint32_t)p->qcoef.size();
+        }
+      }
+    // chunks: the pair table (H2 complex), the per-degree factors of two balls, the slot pointers and the term slice share LDS
+    const int max_pairs = 512;                                     // = FILL_SYM_THREADS: one unit pair per thread
+    const long long budget = 158 * 1024 - (long long)p->H2 * 16 - (long long)2 * n_end * 16 - (long long)(4 * max_pairs + 1) * 4 - 64;
+    long long cap_terms = budget > 0 ? budget / 10 : 0;
+    const long long total = (long long)U * U;
+    p->qchunk.clear(); p->qchunk.push_back(0);
+    p->qchunk_terms_max = 0; p->qchunk_pairs_max = 0;
+    long long e0 = 0;
+    bool fits = cap_terms > 0;
+    while (fits && e0 < total) {
+      long long e1 = e0 + 1;
+      if ((long long)(p->qptr[4 * e1] - p->qptr[4 * e0]) > cap_terms) { fits = false; break; }     // one pair alone exceeds the budget
+      while (e1 < total && e1 - e0 < max_pairs && (long long)(p->qptr[4 * (e1 + 1)] - p->qptr[4 * e0]) <= cap_terms) ++e1;
+      const int nt = (int)(p->qptr[4 * e1] - p->qptr[4 * e0]);
+      if (nt > p->qchunk_terms_max) p->qchunk_terms_max = nt;
+      if ((int)(e1 - e0) > p->qchunk_pairs_max) p->qchunk_pairs_max = (int)(e1 - e0);
+      p->qchunk.push_back((int)e1);
+      e0 = e1;
+    }
+    if (!fits) { p->qchunk.assign(1, 0); p->qchunk_terms_max = 0; p->qchunk_pairs_max = 0; }   // the symmetric fill reports BIEM_ERR_UNSUPPORTED
+  }
   return BIEM_OK;
 }
 
@@ -322,6 +369,12 @@ int plan_upload(biem_plan* p) {
   if ((rc = up(&p->d_tidx, p->tidx))) return rc;
   if ((rc = up(&p->d_tidx16, p->tidx16))) return rc;
   if ((rc = up(&p->d_chunk_ent, p->chunk_ent))) return rc;
+  if ((rc = up(&p->d_spos, p->spos))) return rc;
+  if ((rc = up(&p->d_hpos, p->hpos))) return rc;
+  if ((rc = up(&p->d_qptr, p->qptr))) return rc;
+  if ((rc = up(&p->d_qcoef, p->qcoef))) return rc;
+  if ((rc = up(&p->d_qidx16, p->qidx16))) return rc;
+  if ((rc = up(&p->d_qchunk, p->qchunk))) return rc;
   p->device = dev;
   return BIEM_OK;
 }
@@ -331,6 +384,8 @@ void plan_free(biem_plan* p) {
     (void)hipFree(p->d_labels); (void)hipFree(p->d_deg); (void)hipFree(p->d_labels2); (void)hipFree(p->d_deg2); (void)hipFree(p->d_units);
     (void)hipFree(p->d_W); (void)hipFree(p->d_ptr); (void)hipFree(p->d_coef); (void)hipFree(p->d_tidx);
     (void)hipFree(p->d_tidx16); (void)hipFree(p->d_chunk_ent);
+    (void)hipFree(p->d_spos); (void)hipFree(p->d_hpos); (void)hipFree(p->d_qptr); (void)hipFree(p->d_qcoef); (void)hipFree(p->d_qidx16);
+    (void)hipFree(p->d_qchunk);
   }
   delete p;
 }

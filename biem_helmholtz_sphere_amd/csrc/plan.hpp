@@ -22,6 +22,17 @@ struct biem_plan {
   std::vector<int> chunk_ent;               // fill chunks: entries e = h*H + h' in [chunk_ent[c], chunk_ent[c+1]); sized to the LDS budget
   int chunk_terms_max = 0;                  // largest number of terms in one chunk
   int chunk_ents_max = 0;                   // largest number of entries in one chunk
+  // the symmetric (real-harmonic) fill: unit pairs (u, u') in row-major order, four term lists ("slots") per pair for the entries
+  // (h,h'), (h,p'), (p,h'), (p,p') of the units (h,p), (h',p') - empty where h == p or h' == p' - so one thread forms a whole
+  // 2 x 2 block of R W^H M W R^-1.  Internal order of the unknowns of a ball in that path: the U "cosine" combinations first
+  // (slot u), then the "sine" combinations of the units with h != p (slot U + spos[u]); hpos[h] = slot holding harmonic h before
+  // the transform (h -> u, p -> U + spos[u]).
+  std::vector<int> spos, hpos;              // [U], [H]
+  std::vector<uint32_t> qptr;               // [4 U U + 1]
+  std::vector<double> qcoef;
+  std::vector<uint16_t> qidx16;
+  std::vector<int> qchunk;                  // chunks of unit pairs: [qchunk[c], qchunk[c+1]), at most FILL_SYM_THREADS pairs each
+  int qchunk_terms_max = 0, qchunk_pairs_max = 0;
   // device mirrors (null until uploaded)
   int device = -1;
   int* d_labels = nullptr; int* d_deg = nullptr;
@@ -30,6 +41,8 @@ struct biem_plan {
   double* d_W = nullptr;
   uint32_t* d_ptr = nullptr; double* d_coef = nullptr; int32_t* d_tidx = nullptr;
   uint16_t* d_tidx16 = nullptr; int* d_chunk_ent = nullptr;
+  int* d_spos = nullptr; int* d_hpos = nullptr; uint32_t* d_qptr = nullptr; double* d_qcoef = nullptr; uint16_t* d_qidx16 = nullptr;
+  int* d_qchunk = nullptr;
 };
 
 namespace biem {

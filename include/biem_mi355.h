@@ -46,6 +46,10 @@ extern "C" {
 /* fill scalings */
 #define BIEM_FILL_REFERENCE 0    /* A = blc_{n'} * { diag(alpha h + beta k h') | (S|R)^T (alpha j + beta k j') }  (_biem.py:745-792) */
 #define BIEM_FILL_EQUILIBRATED 1 /* M = I + (S|R)^T (alpha j+beta k j')_row / (alpha h+beta k h')_col : what the LU factors */
+#define BIEM_FILL_SYMMETRIC 2    /* A~ = R W^H M W R^-1, complex symmetric (W: unitary map to real harmonics, R = diag(1/sqrt(gj gh))):
+                                    what the L D L^T path factors.  Rows / columns of a ball in the internal slot order of
+                                    biem_plan_symmetric_order; ONLY the lower triangle and the diagonal 64 x 64 tiles are written
+                                    (n_pad must be a multiple of 64, lda >= n_pad); everything else is left untouched */
 
 /* uscat flags */
 #define BIEM_USCAT_FAR_FIELD 1
@@ -75,6 +79,10 @@ int biem_plan_destroy(biem_plan* plan);
 int biem_plan_info(const biem_plan* plan, int* d, int* n_harm, int* n_quad, int* n_harm2, long long* n_terms);
 /* h_labels[H][3]: a:(m,0,0)  ba:(n,m,0)  bba:(n,l,m)  caa:(n,m1,m2);  h_deg[H]: degree n */
 int biem_plan_labels(const biem_plan* plan, int* h_labels, int* h_deg);
+/* the real-harmonic form used by the symmetric path: h_partner[h] = p with conj Y_h = Y_p (p == h: a real harmonic); h_slot[h] =
+ * internal position of harmonic h among its ball's H unknowns in that path: for a unit (h <= p) the "cosine" combination
+ * (Y_h + Y_p)/sqrt2 sits in slot h_slot[h], the "sine" combination i (Y_p - Y_h)/sqrt2 in slot h_slot[p] */
+int biem_plan_symmetric_order(const biem_plan* plan, int* h_partner /*[H]*/, int* h_slot /*[H]*/);
 /* unit vectors y[Q][d] and weights w[Q] of the boundary-data rule (ush.expand(n=n_end)) */
 int biem_plan_quadrature(const biem_plan* plan, double* h_y, double* h_w);
 /* projection matrix W[Q][H] (complex128, host copy):  f_h = sum_q W[q][h] g(y_q),  W = w_q conj(Y_h(y_q)) */

@@ -420,7 +420,9 @@ def test_factor_once_solve_many_incidences(amd, lib):
                     uin=uin, uin_grad=ugr)
     ms, work, launches = (C.c_double * 9)(), (C.c_double * 9)(), (C.c_longlong * 9)()
     L.check(l.biem_profile_end(ms, work, launches))
-    assert launches[1] == 1 and work[1] == 16.0 * 2 * (3 * 49) ** 2      # ONE fill of K = 2 systems, not R*K = 6
+    tiles = l.biem_lu_npad(3 * 49) // 64
+    per_system = 16.0 * 64 * 64 * tiles * (tiles + 1) / 2             # bytes the symmetric fill writes: lower triangle + diagonal tiles
+    assert launches[1] == 1 and work[1] == 2 * per_system             # ONE fill of K = 2 systems, not R*K = 6
     dens = calc.density
     assert tuple(dens.shape) == (3, 2, 3, 49)
     x = np.array([[5.0, 0.5, 0.2], [-3.0, 2.0, 1.0]])
@@ -695,7 +697,7 @@ def test_ldlt_growth_check_measures_max_u_over_max_a(lib, monkeypatch):
         if limit is None:
             monkeypatch.delenv("BIEM_LDLT_GROWTH_MAX", raising=False)
         else:
-            monkeypatch.setenv("BIEM_LDLT_GROWTH_MAX", repr(limit))
+            monkeypatch.setenv("BIEM_LDLT_GROWTH_MAX", repr(float(limit)))
         A = np.zeros((2, npad, npad + 8), dtype=np.complex128)
         A[:, :N, :N] = As
         A[:, np.arange(N, npad), np.arange(N, npad)] = 1.0
@@ -874,3 +876,66 @@ def test_sharded_solve_on_rccl_world_size_one(amd):
         assert torch.equal(res.density, plain.density)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tree,n_end,B,robin", [("a", 9, 3, False), ("ba", 6, 3, True), ("ba", 12, 2, False), ("bba", 4, 3, True), ("caa", 4, 2, False)])
+def test_symmetric_fill_vs_transformed_general_fill(amd, lib, tree, n_end, B, robin):
+    """BIEM_FILL_SYMMETRIC (what the L D L^T path factors, written once by the fused kernel) against R W^H M W R^-1 formed in
+    NumPy from the general BIEM_FILL_EQUILIBRATED matrix, on everything the factorisation reads (lower triangle + diagonal
+    64 x 64 tiles); the result is complex symmetric and has a unit diagonal."""
+    from biem_helmholtz_sphere_amd import _biem as impl
+
+    l, L = lib
+    d = O.tree(tree).d
+    rng = np.random.default_rng(n_end + B)
+    cen = rng.normal(size=(B, d)) * 0.3 + np.arange(B)[:, None] * np.eye(d)[0] * 2.6
+    rad = rng.uniform(0.6, 1.0, size=B)
+    ks = np.array([0.9, 2.3 + (0.2j if robin else 0.0)])
+    nb = len(ks)
+    plan = impl._plan(tree, n_end, torch.device("cuda", 0))
+    H = plan.H
+    N = B * H
+    npad = l.biem_lu_npad(N)
+    al = _dev(np.full((1, B), 1.0 + 0.0j), torch.complex128)
+    be = _dev(np.full((1, B), (0.4 - 0.1j) if robin else 0.0), torch.complex128)
+    k_t, eta_t = _dev(ks, torch.complex128), _dev(np.ones(nb))
+    cen_t, rad_t = _dev(cen[None]), _dev(rad[None])
+    tab = torch.empty((nb, B, 3, n_end), dtype=torch.complex128, device="cuda")
+    L.check(l.biem_ball_tables(plan.handle, nb, B, k_t.data_ptr(), eta_t.data_ptr(), rad_t.data_ptr(), 0, al.data_ptr(), be.data_ptr(), 0, tab.data_ptr(), None))
+    wb = l.biem_fill_workspace_bytes(plan.handle, nb, B)
+    work = torch.empty(max(wb, 16), dtype=torch.uint8, device="cuda")
+    M = torch.zeros((nb, npad, npad), dtype=torch.complex128, device="cuda")
+    L.check(l.biem_fill(plan.handle, nb, B, k_t.data_ptr(), cen_t.data_ptr(), 0, tab.data_ptr(), L.FILL_EQUILIBRATED, M.data_ptr(), npad, npad * npad, npad, work.data_ptr(), wb, None))
+    S = torch.full((nb, npad, npad), float("nan"), dtype=torch.complex128, device="cuda")
+    L.check(l.biem_fill(plan.handle, nb, B, k_t.data_ptr(), cen_t.data_ptr(), 0, tab.data_ptr(), L.FILL_SYMMETRIC, S.data_ptr(), npad, npad * npad, npad, work.data_ptr(), wb, None))
+    torch.cuda.synchronize()
+    partner = np.zeros(H, dtype=np.int32)
+    slot = np.zeros(H, dtype=np.int32)
+    L.check(l.biem_plan_symmetric_order(plan.handle, partner.ctypes.data, slot.ctypes.data))
+    assert sorted(slot) == list(range(H)) and (partner[partner] == np.arange(H)).all()
+    V = np.zeros((H, H), dtype=np.complex128)
+    sdeg = np.zeros(H, dtype=int)
+    for h in range(H):
+        p = partner[h]
+        if p == h:
+            V[h, slot[h]] = 1.0
+        elif h < p:
+            V[h, slot[h]] = V[p, slot[h]] = 1 / np.sqrt(2)
+            V[p, slot[p]], V[h, slot[p]] = 1j / np.sqrt(2), -1j / np.sqrt(2)
+        sdeg[slot[h]] = plan.degrees[h]
+    Mh, Sh, tabh = M.cpu().numpy(), S.cpu().numpy(), tab.cpu().numpy()
+    blk = np.arange(npad) // 64
+    region = (np.arange(npad)[:, None] >= np.arange(npad)[None, :]) | (blk[:, None] == blk[None, :])
+    for s in range(nb):
+        W = np.eye(npad, dtype=np.complex128)
+        r = np.ones(npad, dtype=np.complex128)
+        for b in range(B):
+            W[b * H:(b + 1) * H, b * H:(b + 1) * H] = V
+            r[b * H:(b + 1) * H] = 1.0 / np.sqrt(tabh[s, b, 0, sdeg] * tabh[s, b, 1, sdeg])
+        want = (r[:, None] * (W.conj().T @ Mh[s] @ W)) / r[None, :]
+        assert np.abs(want - want.T).max() < 1e-13 * np.abs(want).max()           # the structure the path relies on
+        got = Sh[s]
+        assert np.isfinite(got[region]).all()
+        assert np.abs(got[region] - want[region]).max() < 1e-13 * np.abs(want).max(), (tree, s)
+        assert np.abs(np.diag(got) - 1.0).max() < 1e-15
