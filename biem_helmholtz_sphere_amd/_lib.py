@@ -54,6 +54,7 @@ SIGNATURES = {
     "biem_solve": (_i, [_vp, _i, _i, _i, _dp, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _dp, _ip, _i, _vp, _sz, _vp]),
     "biem_solve_ldlt": (_i, [_vp, _i, _i, _i, _dp, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _dp, _ip, _i, _vp, _sz, _vp]),
     "biem_ldlt_factor_solve": (_i, [_i, _i, _i, _dp, _ll, _ll, _ip, _ip, _vp, _sz, _vp]),
+    "biem_sym_factor_solve": (_i, [_i, _i, _i, _dp, _ll, _ll, _ip, _vp, _sz, _vp]),
     "biem_profile_begin": (_i, []),
     "biem_profile_end": (_i, [_vp, _vp, _vp]),
     "biem_bench_mfma_f64": (_i, [_i, C.POINTER(C.c_double), _vp]),

@@ -199,6 +199,12 @@ int biem_lu_solve(int nb, int n_pad, int nrhs, const double* d_LU, long long lda
   return launch_lu_solve(nb, n_pad, nrhs, d_LU, lda, sys_stride, d_ipiv, d_B, ldb, b_stride, (hipStream_t)stream);
 }
 
+int biem_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_info, void* d_work,
+                          size_t work_bytes, void* stream) {
+  NEED(d_A, "d_A"); NEED(d_info, "d_info"); NEED(d_work, "d_work");
+  return launch_sym_factor_solve(nb, n_pad, nrhs, d_A, lda, sys_stride, d_info, d_work, work_bytes, (hipStream_t)stream, false);
+}
+
 int biem_density(const biem_plan* plan, int nb, int B, int nrhs, const double* d_x, long long sys_stride, long long elem_stride,
                  long long rhs_stride, const double* d_tab, double* d_density, void* stream) {
   NEED_DEV(plan); NEED(d_x, "d_x"); NEED(d_tab, "d_tab"); NEED(d_density, "d_density");
@@ -303,8 +309,11 @@ static int solve_impl(const biem_plan* plan, int nb, int B, int nrhs, const doub
       if (rc) return rc;
       amax_ready = true;
     }
-    rc = launch_lu_factor_solve(c, L.n_pad, nrhs, A, L.lda, L.sys_stride, ipiv, d_info + s0, Pw, lu_workspace_bytes(c, L.n_pad, nrhs), st,
-                                /*keep_multipliers=*/false, symmetric, amax_ready);   // the fused path only needs the solution
+    if (symmetric)
+      rc = launch_sym_factor_solve(c, L.n_pad, nrhs, A, L.lda, L.sys_stride, d_info + s0, Pw, lu_workspace_bytes(c, L.n_pad, nrhs), st, amax_ready);
+    else
+      rc = launch_lu_factor_solve(c, L.n_pad, nrhs, A, L.lda, L.sys_stride, ipiv, d_info + s0, Pw, lu_workspace_bytes(c, L.n_pad, nrhs), st,
+                                  /*keep_multipliers=*/false, false, false);   // the fused path only needs the solution
     if (rc) return rc;
     if (symmetric) {
       rc = launch_sym_rhs(plan, c, B, nrhs, L.n_pad, tb, A, L.lda, L.sys_stride, true, st);

@@ -94,6 +94,9 @@ size_t lu_workspace_bytes(int nb, int n_pad, int nrhs);
 int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_ipiv,
                            int* d_info, void* d_work, size_t work_bytes, hipStream_t st, bool keep_multipliers = true,
                            bool symmetric = false, bool amax_ready = false);
+// complex-symmetric A = U^T U in row form on the upper triangle (kernels_lu.hip), fused with the solve of the augmented columns
+int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_info, void* d_work,
+                            size_t work_bytes, hipStream_t st, bool amax_ready = false);
 // where the symmetric factorisation keeps max |A|, max |U| per system inside its workspace (unsigned 64-bit patterns of doubles)
 unsigned long long* lu_growth_slots(void* d_work, int nb, int n_pad);
 // preset the slots for a caller that knows (a lower bound of) max |A|: growth[s] = (amax, 0); then pass amax_ready = true

@@ -329,7 +329,7 @@ int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const doub
 
 // ---------------------------------------------------------------------------------------------
 // Symmetric fill (default path): the complex-symmetric form A~ = R W^H M W R^-1 of the equilibrated system, written ONCE and
-// only where the L D L^T factorisation reads it (lower triangle + the diagonal 64 x 64 tiles) - the general fill followed by
+// only where the symmetric factorisation reads it (UPPER triangle + the diagonal 64 x 64 tiles) - the general fill followed by
 // the in-place symmetrising transform moved 4x the bytes.
 //   W: unitary map to real harmonics (units (h, p), conj Y_h = Y_p: "cosine" (e_h + e_p)/sqrt2, "sine" i (e_p - e_h)/sqrt2),
 //   R = diag(1/sqrt(gj gh)) per (ball, degree).  With q_b[n] = gj / sqrt(gj gh) the block (b, b'), b != b', is
@@ -337,7 +337,7 @@ int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const doub
 // Internal order of a ball's unknowns: slot u = cosine combination of unit u, slot U + spos[u] = its sine combination
 // (plan.hpp); consecutive lanes own consecutive u', so every store instruction covers contiguous runs of a matrix row.
 // One 512-thread workgroup owns a chunk of unit pairs (its four term lists per pair stay in LDS) and loops over
-// (lower ball pair, system) combinations: per combination only the pair table T (H2 complex) is staged - fetched into
+// (upper ball pair b < b', system) combinations: per combination only the pair table T (H2 complex) is staged - fetched into
 // registers during the previous combination's contraction - so the term lists are read from L2 once per workgroup.
 // Each thread runs the four independent chains of its 2 x 2 block (the per-term chain idx -> T -> fma is LDS-latency bound).
 // ---------------------------------------------------------------------------------------------
@@ -383,11 +383,11 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_sym(int H, int U, int
   BIEM_TN_LIST(BIEM_TN_DECL)
 #define BIEM_TN_LOAD(k) if (k < KT) { const int l = k * FILL_SYM_THREADS + tid; tn##k = Tp_[l < H2 ? l : H2 - 1]; }
 #define BIEM_TN_PUT(k) if (k < KT) { const int l = k * FILL_SYM_THREADS + tid; if (l < H2) sT[l] = tn##k; }
-  auto pair_of = [&](int pr, int& b, int& bp) {           // pr-th lower pair (b > bp), row-major over b
+  auto pair_of = [&](int pr, int& b, int& bp) {           // pr-th upper pair (row ball b < column ball bp)
     int bb = (int)((sqrtf(8.0f * (float)pr + 1.0f) + 1.0f) * 0.5f);
     while (bb * (bb - 1) / 2 > pr) --bb;
     while ((bb + 1) * bb / 2 <= pr) ++bb;
-    b = bb; bp = pr - bb * (bb - 1) / 2;
+    bp = bb; b = pr - bb * (bb - 1) / 2;
   };
   auto table_of = [&](int cb) -> const cplx* {
     const int s = cb / npairs, pr = cb - s * npairs;
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_sym(int H, int U, int
     const cplx scale = cmul(sQ[nrow], sQ[n_end + ncol]);
     cplx* As = A + (size_t)s * sys_stride;
     auto put = [&](int rslot, int cslot, cplx val) {
-      const int row = b * H + rslot, col = bp * H + cslot;   // b > bp: strictly below the diagonal
+      const int row = b * H + rslot, col = bp * H + cslot;   // b < bp: strictly above the diagonal
       const cplx w = cmul(val, scale);
       As[(size_t)row * lda + col] = w;
       if ((row >> 6) == (col >> 6)) As[(size_t)col * lda + row] = w;     // a diagonal 64 x 64 tile is read whole: mirror (A~ = A~^T)
@@ -460,14 +460,16 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_sym(int H, int U, int
 }
 
 // what k_fill_sym leaves: the identity diagonal blocks and the padding, again only where the factorisation reads
-// (columns c < 64 (r / 64 + 1) of row r); one workgroup per row
+// (columns c >= 64 (r / 64) of row r); one workgroup per row
 __global__ void __launch_bounds__(64) k_fill_sym_diag(int H, int N, int n_pad, cplx* __restrict__ A, long long lda, long long sys_stride) {
   const int r = blockIdx.x, s = blockIdx.y;
   cplx* row = A + (size_t)s * sys_stride + (size_t)r * lda;
-  const int cend = (r / 64 + 1) * 64;
-  const int br = r / H;
-  for (int c = threadIdx.x; c < cend; c += 64)
-    if (r >= N || c >= N || c / H == br) row[c] = (r == c) ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
+  const int c0 = (r / 64) * 64;
+  auto put = [&](int c) { row[c] = (r == c) ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0); };
+  if (r >= N) { for (int c = c0 + threadIdx.x; c < n_pad; c += 64) put(c); return; }
+  const int br = r / H, bend = (br + 1) * H;              // this row's own ball: columns [br H, bend)
+  for (int c = (c0 > br * H ? c0 : br * H) + threadIdx.x; c < bend; c += 64) put(c);
+  for (int c = N + threadIdx.x; c < n_pad; c += 64) put(c);
 }
 
 // bytes of one system the symmetric path writes and the factorisation reads: sum over rows of 16 * 64 (r / 64 + 1)
@@ -494,7 +496,7 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
       return BIEM_ERR_UNSUPPORTED;
     }
     hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2, p->d_deg2, B,
-                       (const cplx*)d_k, d_centers, geom_batched, T, 1);
+                       (const cplx*)d_k, d_centers, geom_batched, T, 0);
     BIEM_LAUNCHCHK();
 
     const int npairs = B * (B - 1) / 2;

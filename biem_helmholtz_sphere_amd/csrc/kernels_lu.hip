@@ -33,8 +33,9 @@ size_t lu_workspace_bytes(int nb, int n_pad, int nrhs) {
   // + the tile map of the triangular (symmetric) update: one int per lower-triangle tile of the largest trailing matrix
   const size_t T = (size_t)n_pad / NB;
   // + two doubles per system: max |A| over what the symmetric factorisation reads and max |U| (a-posteriori growth check)
+  // (the row-panel form of the symmetric path needs no panels, only (64 x 64 + 64) complex per system; one layout serves all)
   return (size_t)nb * (4 * NB * (size_t)ldp_of(n_pad) + (size_t)NB * NB) * sizeof(cplx) + ((T * (T + 1) / 2 + 63) / 64) * 64 * sizeof(int) +
-         (size_t)nb * 2 * sizeof(double);
+         (size_t)nb * 2 * sizeof(double) + (size_t)nb * NB * sizeof(cplx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -54,7 +55,8 @@ __device__ inline void block_max_publish(double m, unsigned long long* dst) {   
   __syncthreads();
   if (threadIdx.x == 0) {
     m = nan_max(nan_max(sm_max[0], sm_max[1]), nan_max(sm_max[2], sm_max[3]));
-    atomicMax(dst, (unsigned long long)__double_as_longlong(m));
+    // most workgroups cannot raise the maximum: a plain read filters them out (the slot only grows, so a stale value is safe)
+    if (!(m <= __longlong_as_double((long long)*(volatile unsigned long long*)dst))) atomicMax(dst, (unsigned long long)__double_as_longlong(m));
   }
 }
 // max |A| over the lower triangle and the diagonal 64 x 64 blocks: 8 rows per workgroup, coalesced along the row
@@ -393,7 +395,7 @@ struct TileGrid {
   // tiles of tile column `pcol_tx` deliver their result transposed into the panel workspace (the next panel to factor:
   // column-major P[c][row]) instead of the matrix, which saves that panel's transposing load; pout == nullptr: off
   cplx* pout; long long pout_ld, pout_stride; int pcol_tx;
-  int tri;                                      // 1: only tiles with tx <= ty (square region, symmetric update)
+  int tri;                                      // 1: only tiles with tx <= ty (square region, symmetric update); 2: only tx >= ty
   const int* tri_map; int tri_full;             // (ty << 16 | tx) of the first tri_full tiles of that order (the full bands)
   unsigned long long per_sys_magic;             // ceil(2^40 / per_sys): t / per_sys = (t * magic) >> 40 for t < 2^25 (scalar multiply, no VALU division)
 };
@@ -428,6 +430,7 @@ __device__ inline void tile_decode(const TileGrid& tg, int t, int& s, int& ty, i
   if (tg.tri) {
     if (r < tg.tri_full) { const int v = tg.tri_map[r]; ty = v >> 16; tx = v & 0xffff; }
     else tri_decode_band(r, tg.full_bands, tg.ty_n - 8 * tg.full_bands, ty, tx);      // the partial last band
+    if (tg.tri == 2) { const int t2 = ty; ty = tx; tx = t2; }                          // upper triangle: the mirror tile
     return;
   }
   int fb = tg.full_bands * 8 * tg.tx_n;
@@ -984,8 +987,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
 static int launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, long long sys_stride, const cplx* Pw, long long ldp,
                                long long p_stride, int row_begin, int row_end, int col_begin, int col_end, int brow, int kd,
                                int prof_class = PK_GEMM, double prof_work = -1.0, cplx* pout = nullptr, long long pout_ld = 0,
-                               long long pout_stride = 0, int pcol_tx = 0, const int* tri_map = nullptr) {
-  const int tri = tri_map != nullptr;
+                               long long pout_stride = 0, int pcol_tx = 0, const int* tri_map = nullptr, bool upper = false) {
+  const int tri = tri_map != nullptr ? (upper ? 2 : 1) : 0;
   const int rrows = row_end - row_begin, rcols = col_end - col_begin;
   if (rrows <= 0 || rcols <= 0) return BIEM_OK;
   TileGrid tg;
@@ -1105,14 +1108,35 @@ __global__ void __launch_bounds__(64) k_fwd_diag(const cplx* __restrict__ A, lon
 // rows [row_begin, row_end): y[i] -= M[i, jr:jr+64] . x[jr:jr+64]; one wave per row (back substitution: the rows above the
 // solved block with M = U; forward substitution with stored factors: the rows below the panel with M = L)
 constexpr int BACK_ROWS = 16;   // rows per workgroup (4 per wave)
+// With `info` given (row form of the symmetric path) the pass also checks the entries it reads, u_ic of the strips right of the diagonal
+// blocks: |u_ic|^2 <= inv_rel2 |u_ii|^2 (every multiplier l_ci = u_ic / u_ii within 1 / rel; NaN-safe) else info = -(first row of the
+// 64-row panel + 1), and max |u_ii u_ic| into the growth slot.
 __global__ void __launch_bounds__(256) k_back_update(const cplx* __restrict__ A, long long lda, long long sys_stride, cplx* __restrict__ F,
-                                                      long long ldf, long long f_stride, int nrhs, int jr, int row_begin, int row_end) {
+                                                      long long ldf, long long f_stride, int nrhs, int jr, int row_begin, int row_end,
+                                                      int* __restrict__ info = nullptr, unsigned long long* __restrict__ growth = nullptr,
+                                                      double inv_rel2 = 0.0) {
   // The 64 solution values are strided by ldf in memory (one cache line each): they are gathered ONCE per workgroup into LDS
   // instead of once per row
   __shared__ cplx sx[BS];
   const int s = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const cplx* As = A + (size_t)s * sys_stride;
   cplx* Fs = F + (size_t)s * f_stride;
+  if (info != nullptr) {
+    double um2 = 0.0;
+    bool badm = false;
+    int bad_row = 0;
+#pragma unroll
+    for (int k = 0; k < BACK_ROWS / 4; ++k) {
+      const int i = row_begin + blockIdx.x * BACK_ROWS + wave * (BACK_ROWS / 4) + k;
+      if (i >= row_end) break;
+      const cplx u = As[(size_t)i * lda + jr + lane], d = As[(size_t)i * lda + i];
+      const double m2 = u.x * u.x + u.y * u.y, d2 = d.x * d.x + d.y * d.y;
+      if (!(m2 <= inv_rel2 * d2)) { badm = true; bad_row = i; }
+      um2 = nan_max(um2, m2 * d2);
+    }
+    block_max_publish(sqrt(um2), growth + 2 * (size_t)s + 1);
+    if (badm && info[s] == 0) info[s] = -((bad_row / NB) * NB + 1);
+  }
   for (int q = 0; q < nrhs; ++q) {
     if (q > 0) __syncthreads();
     if (threadIdx.x < BS) sx[threadIdx.x] = Fs[(size_t)(jr + threadIdx.x) * ldf + q];
@@ -1518,6 +1542,179 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
     }
     BIEM_LAUNCHCHK();
   }
+  return BIEM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Symmetric path in ROW form (what biem_solve_ldlt runs):  A = U^T U  with U = D^{1/2} L^T upper triangular, the complex-symmetric
+// analogue of the Cholesky factorisation (no conjugation, principal complex square roots of the pivots; same pivots, same
+// multipliers l_ci = u_ic / u_ii and same acceptance test as the L D L^T form it replaces).  Why this form: with A = U^T U the
+// trailing update  A22 -= U12^T U12  takes BOTH zgemm operands from the same 64-row strip of the row-major matrix
+// (A-operand[k][i] = U12[k][row i], B-operand[k][c] = U12[k][col c]), which is also exactly what the back substitution reads.
+// So the factorisation works in place on the upper triangle: no column-major panel workspace, no transposing panel load / store,
+// no transposed GEMM epilogue, no separate "U rows from L" pass - a panel is two passes over its strip instead of about six.
+//   k_diag_utu  (one workgroup per system): the 64 x 64 diagonal block: pivots d, U11 = D^{-1/2} (D L11^T), W = I - U11^{-T},
+//               multiplier test inside the block
+//   strip:      U12 = U11^{-T} A12 = A12 - W A12 in place on the streaming zgemm (K = 64, B operand = the strip's own rows; the
+//               right-hand-side columns are columns of the strip: forward elimination rides along).  A one-thread-per-column
+//               VALU form with the triangle of U11^{-T} from the scalar cache or LDS was 5x slower (292 vs 53 ms per 256 systems)
+//   checks:     multiplier test |u_ic| <= 2 |u_ii| and growth max |u_ii u_ic| of the strip entries are taken where the entries
+//               are read anyway: in the back substitution (k_back_update)
+//   in-group:   the next panel's 64 rows take the group's pending updates (K = 64 q) for all columns right of them
+//   K = 256:    one update of the UPPER triangle of tiles below the group (TileGrid.tri = 2), right-hand sides by k_rhs_update
+// Only the upper triangle and the diagonal 64 x 64 tiles of A are read.  Growth check as in the L D L^T form, with moduli:
+// max |d_i l_ci| = max |u_ii u_ic| against max |a_ij| over the part read.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_absmax_upper(const cplx* __restrict__ A, long long lda, long long sys_stride, int n_pad,
+                                                       unsigned long long* __restrict__ growth) {
+  const int s = blockIdx.y;
+  const cplx* As = A + (size_t)s * sys_stride;
+  double m = 0.0;
+  for (int r = 0; r < 8; ++r) {
+    const int i = blockIdx.x * 8 + r;
+    if (i >= n_pad) break;
+    for (int c = (i / NB) * NB + threadIdx.x; c < n_pad; c += 256) { const cplx v = As[(size_t)i * lda + c]; m = nan_max(m, sqrt(v.x * v.x + v.y * v.y)); }
+  }
+  block_max_publish(m, growth + 2 * (size_t)s);
+}
+
+__global__ void __launch_bounds__(256) k_diag_utu(cplx* __restrict__ A, long long lda, long long sys_stride, int j, cplx* __restrict__ Wt,
+                                                   int* __restrict__ info, double rel, unsigned long long* __restrict__ growth) {
+  // elimination and inverse exactly as k_diag_nopiv (row r = tid & 63, part = tid >> 6), on a[c][r] = block column c, row r
+  __shared__ cplx a[NB][NB + 1];
+  __shared__ cplx x[NB][NB + 1];     // x[k][c] = ((D L11^T)^{-1})[k][c]
+  __shared__ cplx red[4][NB];
+  __shared__ cplx ssq[NB];           // s_c = sqrt(d_c)
+  __shared__ int bad;
+  const int s = blockIdx.x, tid = threadIdx.x, r = tid & 63, part = tid >> 6;
+  cplx* Ab = A + (size_t)s * sys_stride + (size_t)j * lda + j;
+  if (tid == 0) bad = 0;
+  for (int rr = part; rr < NB; rr += 4) { a[r][rr] = Ab[(size_t)rr * lda + r]; x[rr][r] = make_double2(0.0, 0.0); }   // lanes along the row: coalesced
+  __syncthreads();
+  for (int c = 0; c < NB; ++c) {
+    const cplx piv = a[c][c];
+    const double pa = fabs(piv.x) + fabs(piv.y);
+    cplx l = make_double2(0.0, 0.0);
+    if (r > c) {
+      const cplx v = a[c][r];
+      if (part == 0 && !(pa >= rel * (fabs(v.x) + fabs(v.y)))) bad = 1;
+      l = cmul(v, crecip(piv));
+      for (int c2 = c + 1 + part; c2 < NB; c2 += 4) a[c2][r] = cfnma(l, a[c2][c], a[c2][r]);
+    } else if (r == c && part == 0 && !(pa > 0.0)) bad = 1;
+    __syncthreads();
+    if (r > c && part == 0) a[c][r] = l;
+  }
+  __syncthreads();
+  for (int d = 0; d < NB; ++d) {
+    const int k = r, c = r + d;
+    cplx acc = make_double2(0.0, 0.0);
+    if (c < NB)
+      for (int m = k + 1 + part; m <= c; m += 4) acc = cfma(a[m][k], x[m][c], acc);
+    red[part][r] = acc;
+    __syncthreads();
+    if (part == 0 && c < NB) {
+      cplx sum = red[0][r];
+      sum.x += red[1][r].x + red[2][r].x + red[3][r].x; sum.y += red[1][r].y + red[2][r].y + red[3][r].y;
+      cplx rhs = (d == 0) ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
+      rhs.x -= sum.x; rhs.y -= sum.y;
+      x[k][c] = cmul(rhs, crecip(a[k][k]));
+    }
+    __syncthreads();
+  }
+  if (tid < NB) ssq[tid] = zsqrt(a[tid][tid]);
+  __syncthreads();
+  // U11[rr][c] = (D L11^T)[rr][c] / s_rr for c >= rr, back into the matrix (lanes along the row); growth of the D L^T entries
+  double um = 0.0;
+  for (int rr = part; rr < NB; rr += 4) {
+    const int c = r;
+    if (c >= rr) { const cplx u = a[c][rr]; um = nan_max(um, sqrt(u.x * u.x + u.y * u.y)); Ab[(size_t)rr * lda + c] = cmul(u, crecip(ssq[rr])); }
+  }
+  block_max_publish(um, growth + 2 * (size_t)s + 1);
+  // W = I - X^T, X^T = U11^{-T} (X^T[i][k] = x[k][i] s_i, k <= i), stored [k][i] - the A-operand order of the streaming zgemm, which
+  // then forms the strip in place:  U12 = X^T A12 = A12 - W A12   (lanes along i: coalesced)
+  cplx* Wo = Wt + (size_t)s * NB * NB;
+  for (int k = part; k < NB; k += 4) {
+    cplx w = make_double2(0.0, 0.0);
+    if (k <= r) { const cplx xt = cmul(x[k][r], ssq[r]); w = make_double2((k == r ? 1.0 : 0.0) - xt.x, -xt.y); }
+    Wo[k * NB + r] = w;
+  }
+  if (tid == 0 && bad && info[s] == 0) info[s] = -(j + 1);
+}
+
+int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_info, void* d_work,
+                            size_t work_bytes, hipStream_t st, bool amax_ready) {
+  if (nb <= 0 || n_pad <= 0) return BIEM_OK;
+  if (n_pad % NB) { set_error("biem_sym: n_pad=%d is not a multiple of %d (use biem_lu_npad)", n_pad, NB); return BIEM_ERR_ARG; }
+  if (nrhs < 0 || lda < n_pad + nrhs) { set_error("biem_sym: lda < n_pad + nrhs"); return BIEM_ERR_ARG; }
+  if (nb > 65535 || nrhs > 65535) { set_error("biem_sym: at most 65535 systems / right-hand sides per call (got %d / %d)", nb, nrhs); return BIEM_ERR_ARG; }
+  if (work_bytes < lu_workspace_bytes(nb, n_pad, nrhs)) { set_error("biem_sym: workspace too small"); return BIEM_ERR_ARG; }
+  cplx* A = (cplx*)d_A;
+  const int n_cols = n_pad + nrhs;
+  cplx* Wt = (cplx*)d_work + (size_t)nb * 4 * NB * (size_t)ldp_of(n_pad);      // same place as the 64 x 64 block of the other paths
+  int* tri_map = (int*)(Wt + (size_t)nb * NB * NB);
+  unsigned long long* growth = lu_growth_slots(d_work, nb, n_pad);
+  hipLaunchKernelGGL(k_zero_int, dim3((nb + 63) / 64), dim3(64), 0, st, d_info, nb);
+  double nopiv = NOPIV_REL, growth_max = GROWTH_MAX;
+  { const char* e = getenv("BIEM_LDLT_PIVOT_REL"); if (e && atof(e) > 0.0) nopiv = atof(e);
+    const char* g = getenv("BIEM_LDLT_GROWTH_MAX"); if (g && atof(g) > 0.0) growth_max = atof(g); }
+  {
+    const int T = n_pad / NB, fb = T / 8, n_map = 32 * fb * fb + 4 * fb;
+    if (n_map > 0) hipLaunchKernelGGL(k_tri_map, dim3((n_map + 255) / 256), dim3(256), 0, st, tri_map, n_map);
+  }
+  if (!amax_ready) {
+    hipLaunchKernelGGL(k_zero_int, dim3((4 * nb + 63) / 64), dim3(64), 0, st, (int*)growth, 4 * nb);
+    ProfScope ps(PK_SWAP, st, 0.0);
+    hipLaunchKernelGGL(k_absmax_upper, dim3((n_pad + 7) / 8, nb), dim3(256), 0, st, A, lda, sys_stride, n_pad, growth);
+  }
+  int gemm_rc = BIEM_OK;
+  auto gemm = [&](auto&&... a) { const int r = launch_gemm_stream(a...); if (r != BIEM_OK && gemm_rc == BIEM_OK) gemm_rc = r; };
+  const bool rhs_gemv = nrhs > 0 && nrhs <= 8;
+  auto panel = [&](int j) {
+    {
+      ProfScope ps(PK_PANEL, st, 0.0);
+      hipLaunchKernelGGL(k_diag_utu, dim3(nb), dim3(256), 0, st, A, lda, sys_stride, j, Wt, d_info, nopiv, growth);
+    }
+    // A operand W[k][i], i = row - j: the base shifted by -j rows (only rows j .. j+63 are addressed)
+    if (n_cols > j + NB)
+      gemm(st, nb, A, lda, sys_stride, Wt - j, NB, (long long)NB * NB, j, j + NB, j + NB, n_cols, j, NB, PK_PANEL, 8.0 * (double)nb * (n_cols - j - NB) * NB * NB);
+  };
+  for (int J = 0; J < n_pad; J += 4 * NB) {
+    const cplx* strip = A + (size_t)J * lda;        // both operands of this group's updates: rows J .. of the matrix itself
+    panel(J);
+    for (int q = 1; q < 4; ++q) {
+      const int jq = J + q * NB;
+      if (jq >= n_pad) break;
+      // the next panel's 64 rows: all pending updates of the group (K = 64 q), every column right of them incl. the right-hand sides
+      gemm(st, nb, A, lda, sys_stride, strip, lda, sys_stride, jq, jq + NB, jq, n_cols, J, q * NB, PK_OTHER);
+      panel(jq);
+    }
+    if (J + 4 * NB >= n_pad) break;
+    gemm(st, nb, A, lda, sys_stride, strip, lda, sys_stride, J + 4 * NB, n_pad, J + 4 * NB, n_pad, J, 4 * NB, PK_GEMM, -1.0, nullptr, 0, 0, 0,
+         tri_map, true);
+    if (rhs_gemv) {
+      ProfScope ps(PK_OTHER, st, 0.0);
+      hipLaunchKernelGGL(k_rhs_update, dim3((n_pad - (J + 4 * NB) + 255) / 256, nb, nrhs), dim3(256), 0, st, A, lda, sys_stride, strip, lda,
+                         sys_stride, n_pad, J + 4 * NB, J, 4 * NB);
+    } else if (nrhs > 0) {
+      gemm(st, nb, A, lda, sys_stride, strip, lda, sys_stride, J + 4 * NB, n_pad, n_pad, n_cols, J, 4 * NB, PK_OTHER);
+    }
+  }
+  BIEM_LAUNCHCHK();
+  if (gemm_rc != BIEM_OK) return gemm_rc;
+  {
+    // back substitution; its pass over U also takes the multiplier / growth checks of the strip entries (nrhs == 0: the pass runs
+    // for the checks alone)
+    ProfScope ps(PK_BACK, st, 4.0 * (double)nb * n_pad * (double)n_pad * nrhs);
+    for (int jr = n_pad - BS; jr >= 0; jr -= BS) {
+      if (nrhs > 0) hipLaunchKernelGGL(k_back_diag, dim3(nb, nrhs), dim3(64), 0, st, A, lda, sys_stride, A + n_pad, lda, sys_stride, jr);
+      if (jr > 0)
+        hipLaunchKernelGGL(k_back_update, dim3((jr + BACK_ROWS - 1) / BACK_ROWS, nb), dim3(256), 0, st, A, lda, sys_stride, A + n_pad, lda,
+                           sys_stride, nrhs, jr, 0, jr, d_info, growth, 1.0 / (nopiv * nopiv));
+    }
+    BIEM_LAUNCHCHK();
+  }
+  hipLaunchKernelGGL(k_growth_check, dim3((nb + 63) / 64), dim3(64), 0, st, nb, n_pad, growth, d_info, growth_max);
+  BIEM_LAUNCHCHK();
   return BIEM_OK;
 }
 

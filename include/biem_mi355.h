@@ -48,7 +48,7 @@ extern "C" {
 #define BIEM_FILL_EQUILIBRATED 1 /* M = I + (S|R)^T (alpha j+beta k j')_row / (alpha h+beta k h')_col : what the LU factors */
 #define BIEM_FILL_SYMMETRIC 2    /* A~ = R W^H M W R^-1, complex symmetric (W: unitary map to real harmonics, R = diag(1/sqrt(gj gh))):
                                     what the L D L^T path factors.  Rows / columns of a ball in the internal slot order of
-                                    biem_plan_symmetric_order; ONLY the lower triangle and the diagonal 64 x 64 tiles are written
+                                    biem_plan_symmetric_order; ONLY the upper triangle and the diagonal 64 x 64 tiles are written
                                     (n_pad must be a multiple of 64, lda >= n_pad); everything else is left untouched */
 
 /* uscat flags */
@@ -165,6 +165,15 @@ int biem_ldlt_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
                            int* d_ipiv /*[nb][n_pad], identity on return*/, int* d_info /*[nb]*/, void* d_work, size_t work_bytes,
                            void* stream);
 
+/* The same systems in ROW form, which is what biem_solve_ldlt runs: A = U^T U, U upper triangular (the complex-symmetric analogue
+ * of Cholesky: U = D^{1/2} L^T with the L, D above; principal complex square roots, no conjugation, no interchanges).  Both
+ * operands of every trailing update come from a 64-row strip of the row-major matrix itself, so the factorisation works in place
+ * on the UPPER triangle: only the upper triangle and the diagonal 64 x 64 tiles of A are read; on return they hold U, the
+ * augmented columns the solutions.  Same workspace size, d_info codes (rejected multiplier: -(first row of the 64-row panel + 1);
+ * growth: -(Npad + 1)) and acceptance tests as biem_ldlt_factor_solve. */
+int biem_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_info /*[nb]*/,
+                          void* d_work, size_t work_bytes, void* stream);
+
 /* density[s][r][b][h] = x / (gh * blc): the reference's `density` from the equilibrated unknowns (also the
  * single-ball shortcut _biem.py:648-691 with x = f).  x element (s, r, i) at d_x[s*sys_stride + i*elem_stride + r*rhs_stride]. */
 int biem_density(const biem_plan* plan, int nb, int B, int nrhs, const double* d_x, long long sys_stride, long long elem_stride,
@@ -188,8 +197,8 @@ int biem_solve(const biem_plan* plan, int nb, int B, int nrhs, const double* d_k
 
 /* The same through the complex-symmetric form of the system: with W the unitary map to real harmonics and
  * R = diag(1/sqrt(gj gh)), R W^H M W R^-1 is complex symmetric (the reference solves the general system with LU,
- * _biem.py:797; the symmetry is a property of (S|R), tests/test_oracle_golden.py).  Fill, symmetrise in place, L D L^T without
- * interchanges, back-transform, density.  d_info[s] < 0: a diagonal pivot was rejected (see biem_ldlt_factor_solve) - the caller
+ * _biem.py:797; the symmetry is a property of (S|R), tests/test_oracle_golden.py).  Symmetric fill (upper triangle), U^T U
+ * factorisation without interchanges (biem_sym_factor_solve), back-transform, density.  d_info[s] < 0: a diagonal pivot was rejected (see biem_ldlt_factor_solve) - the caller
  * re-solves those systems with biem_solve.  Same arguments and workspace as biem_solve. */
 int biem_solve_ldlt(const biem_plan* plan, int nb, int B, int nrhs, const double* d_k /*c128*/, const double* d_eta,
                     const double* d_centers, const double* d_radii, int geom_batched, const double* d_alpha, const double* d_beta,

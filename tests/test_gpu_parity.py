@@ -882,7 +882,7 @@ def test_sharded_solve_on_rccl_world_size_one(amd):
 @pytest.mark.parametrize("tree,n_end,B,robin", [("a", 9, 3, False), ("ba", 6, 3, True), ("ba", 12, 2, False), ("bba", 4, 3, True), ("caa", 4, 2, False)])
 def test_symmetric_fill_vs_transformed_general_fill(amd, lib, tree, n_end, B, robin):
     """BIEM_FILL_SYMMETRIC (what the L D L^T path factors, written once by the fused kernel) against R W^H M W R^-1 formed in
-    NumPy from the general BIEM_FILL_EQUILIBRATED matrix, on everything the factorisation reads (lower triangle + diagonal
+    NumPy from the general BIEM_FILL_EQUILIBRATED matrix, on everything the factorisation reads (upper triangle + diagonal
     64 x 64 tiles); the result is complex symmetric and has a unit diagonal."""
     from biem_helmholtz_sphere_amd import _biem as impl
 
@@ -926,7 +926,7 @@ def test_symmetric_fill_vs_transformed_general_fill(amd, lib, tree, n_end, B, ro
         sdeg[slot[h]] = plan.degrees[h]
     Mh, Sh, tabh = M.cpu().numpy(), S.cpu().numpy(), tab.cpu().numpy()
     blk = np.arange(npad) // 64
-    region = (np.arange(npad)[:, None] >= np.arange(npad)[None, :]) | (blk[:, None] == blk[None, :])
+    region = (np.arange(npad)[:, None] <= np.arange(npad)[None, :]) | (blk[:, None] == blk[None, :])      # upper triangle + diagonal tiles
     for s in range(nb):
         W = np.eye(npad, dtype=np.complex128)
         r = np.ones(npad, dtype=np.complex128)
@@ -939,3 +939,89 @@ def test_symmetric_fill_vs_transformed_general_fill(amd, lib, tree, n_end, B, ro
         assert np.isfinite(got[region]).all()
         assert np.abs(got[region] - want[region]).max() < 1e-13 * np.abs(want).max(), (tree, s)
         assert np.abs(np.diag(got) - 1.0).max() < 1e-15
+
+
+# ---------------------------------------------------------------------------- the row-form symmetric factorisation (default path)
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,nb,nrhs", [(64, 2, 1), (150, 2, 2), (256, 1, 1), (300, 3, 1), (576, 2, 3), (1000, 2, 1), (1345, 1, 2), (700, 2, 12), (130, 1, 70)])
+def test_sym_factor_solve_vs_numpy(lib, N, nb, nrhs):
+    """biem_sym_factor_solve (A = U^T U in row form, what biem_solve_ldlt runs) on complex-symmetric matrices I + E against
+    numpy.linalg.solve; only the UPPER triangle and the diagonal tiles may be read: the strict lower triangle outside the
+    diagonal 64 x 64 tiles is poisoned.  On return the upper triangle holds U with U^T U = A."""
+    l, L = lib
+    rng = np.random.default_rng(N + 11)
+    npad = l.biem_lu_npad(N)
+    lda = npad + ((nrhs + 7) // 8) * 8
+    E = (rng.normal(size=(nb, N, N)) + 1j * rng.normal(size=(nb, N, N))) * (0.12 / np.sqrt(N))
+    As = np.eye(N)[None] * (1.0 + 0.2j) + E + np.swapaxes(E, 1, 2)
+    Fs = rng.normal(size=(nb, N, nrhs)) + 1j * rng.normal(size=(nb, N, nrhs))
+    A = np.zeros((nb, npad, lda), dtype=np.complex128)
+    A[:, :N, :N] = As
+    for i in range(N, npad):
+        A[:, i, i] = 1.0
+    blk = np.arange(npad) // 64
+    lower_off = (blk[:, None] > blk[None, :])
+    A[:, :npad, :npad][:, lower_off] = 1e30                    # must never be read
+    A[:, :N, npad:npad + nrhs] = Fs
+    dA = _dev(A, torch.complex128)
+    info = torch.ones(nb, dtype=torch.int32, device="cuda")
+    wb = l.biem_lu_workspace_bytes(nb, npad, nrhs)
+    work = torch.empty(wb, dtype=torch.uint8, device="cuda")
+    L.check(l.biem_sym_factor_solve(nb, npad, nrhs, dA.data_ptr(), lda, npad * lda, info.data_ptr(), work.data_ptr(), wb, None))
+    torch.cuda.synchronize()
+    assert (info.cpu().numpy() == 0).all(), info.cpu().numpy()
+    out = dA.cpu().numpy()
+    X = out[:, :N, npad:npad + nrhs]
+    for s in range(nb):
+        Xo = np.linalg.solve(As[s], Fs[s])
+        assert np.abs(X[s] - Xo).max() / np.abs(Xo).max() < 1e-12, (N, s)
+        U = np.triu(out[s, :N, :N])
+        assert np.abs(U.T @ U - As[s]).max() < 1e-12, (N, s)
+
+
+@pytest.mark.gpu
+def test_sym_factor_rejections_and_growth(lib, monkeypatch):
+    """Acceptance tests of the row form: a diagonal below half of an entry of its row (a multiplier above 2) marks the system with
+    the panel's first row; max |u_ii u_ic| / max |a_ij| (moduli) equals the NumPy value - limits 1 % below / above it mark / pass
+    the system (info = -(Npad + 1)); a NaN marks it at the default limit."""
+    l, L = lib
+
+    def run(A, nrhs=1):
+        nb, npad = A.shape[0], A.shape[1]
+        dA = _dev(A, torch.complex128)
+        info = torch.zeros(nb, dtype=torch.int32, device="cuda")
+        wb = l.biem_lu_workspace_bytes(nb, npad, nrhs)
+        work = torch.empty(wb, dtype=torch.uint8, device="cuda")
+        L.check(l.biem_sym_factor_solve(nb, npad, nrhs, dA.data_ptr(), A.shape[2], npad * A.shape[2], info.data_ptr(), work.data_ptr(), wb, None))
+        torch.cuda.synchronize()
+        return info.cpu().tolist()
+
+    N = 128
+    A = np.zeros((3, N, N + 8), dtype=np.complex128)
+    A[:, :, :N] = np.eye(N)
+    A[1, 70, 70] = 0.01
+    A[1, 90, 70] = A[1, 70, 90] = 1.0                           # inside the second diagonal block
+    A[2, 10, 10] = 0.01
+    A[2, 10, 100] = A[2, 100, 10] = 1.0                         # multiplier in the strip right of the first block
+    assert run(A) == [0, -65, -1]
+    N, npad = 200, 256
+    rng = np.random.default_rng(5)
+    E = (rng.normal(size=(N, N)) + 1j * rng.normal(size=(N, N))) * (0.12 / np.sqrt(N))
+    As = np.eye(N) * (1.0 + 0.2j) + E + E.T
+    M = As.copy()
+    for c in range(N):
+        M[c + 1:, c] /= M[c, c]
+        M[c + 1:, c + 1:] -= np.outer(M[c + 1:, c], M[c, c + 1:])
+    ratio = np.abs(np.triu(M)).max() / np.abs(As).max()
+    B = np.zeros((2, npad, npad + 8), dtype=np.complex128)
+    B[:, :N, :N] = As
+    B[:, np.arange(N, npad), np.arange(N, npad)] = 1.0
+    B[:, :N, npad] = 1.0
+    monkeypatch.setenv("BIEM_LDLT_GROWTH_MAX", repr(float(0.99 * ratio)))
+    assert run(B) == [-(npad + 1)] * 2
+    monkeypatch.setenv("BIEM_LDLT_GROWTH_MAX", repr(float(1.01 * ratio)))
+    assert run(B) == [0, 0]
+    monkeypatch.delenv("BIEM_LDLT_GROWTH_MAX")
+    B[1, 20, 150] = np.nan
+    bad = run(B)
+    assert bad[0] == 0 and bad[1] < 0
