@@ -3,6 +3,7 @@
 // Replaces the span _biem.py:627-639 (RHS) and _biem.py:694-792 (matrix) of the reference, which there is
 // ~40 array-API ops and 3-5 full-size temporaries; here every matrix element is written exactly once.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace biem {
 
@@ -144,7 +145,7 @@ int launch_ball_tables(const biem_plan* p, int nb, int B, const double* d_k, con
 __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int H2, double Cd, const int* __restrict__ labels2,
                                                      const int* __restrict__ deg2, int B, const cplx* __restrict__ k,
                                                      const double* __restrict__ centers, int geom_batched, cplx* __restrict__ T,
-                                                     int lower) {
+                                                     int lower, int nbp) {
   __shared__ cplx sJ[kMaxRad * 2 + 6];
   __shared__ cplx sH[kMaxRad * 2 + 6];
   int pair = blockIdx.x, s = blockIdx.y;
@@ -160,12 +161,16 @@ __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int
   if (threadIdx.x == 0) radial_jh(d, n2 - 1, cscale(k[s], r), sJ, sH);
   __syncthreads();
   Dir dir = make_dir(tree, t);
-  cplx* out = T + ((size_t)s * B * B + pair) * H2;
+  // nbp > 0: systems-in-lanes layout Tt[group of 64 systems][pair index of (b < bp)][l][system in group]: a group's table rows are
+  // contiguous 1-KiB lines (with the systems of ALL groups in one row, the rows one group reads lie 4 KiB apart and every
+  // workgroup of a fill - they all work on the same group at a time - hits the same quarter of the L2 channels)
+  cplx* out = nbp > 0 ? T + (((size_t)(s >> 6) * (B * (B - 1) / 2) + (bp * (bp - 1) / 2 + b)) * H2) * 64 + (s & 63) : T + ((size_t)s * B * B + pair) * H2;
+  const size_t ostride = nbp > 0 ? 64 : 1;
   for (int l = threadIdx.x; l < H2; l += 64) {
     double re, im;
     harmonic_single(tree, labels2[3 * l], labels2[3 * l + 1], labels2[3 * l + 2], dir, &re, &im);
     int n = deg2[l];
-    out[l] = cmul(cscale(sH[n], Cd), make_double2(re, im));
+    out[(size_t)l * ostride] = cmul(cscale(sH[n], Cd), make_double2(re, im));
   }
 }
 
@@ -291,7 +296,12 @@ __global__ void k_fill_pad(int N, int n_pad, cplx* __restrict__ A, long long lda
   }
 }
 
-size_t fill_workspace_bytes(const biem_plan* p, int nb, int B) { return (size_t)nb * B * B * p->H2 * sizeof(cplx); }
+size_t fill_workspace_bytes(const biem_plan* p, int nb, int B) {
+  // pair tables of the general / entry forms: [nb][B][B][H2]; of the systems-in-lanes form: [nb rounded up to 64][pairs][H2] + q factors
+  const size_t a = (size_t)nb * B * B * p->H2, nbp = (size_t)(nb + 63) / 64 * 64;
+  const size_t b = ((size_t)(B * (B - 1) / 2) * p->H2 + (size_t)B * p->n_end) * nbp;
+  return (a > b ? a : b) * sizeof(cplx);
+}
 
 int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const double* d_centers, int geom_batched,
                 const double* d_tab, int scaling, double* d_A, long long lda, long long sys_stride, int n_pad,
@@ -306,7 +316,7 @@ int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const doub
   ProfScope ps(PK_FILL, st, 16.0 * (double)nb * N * (double)N);
   if (B > 1) {
     hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2,
-                       p->d_deg2, B, (const cplx*)d_k, d_centers, geom_batched, T, 0);
+                       p->d_deg2, B, (const cplx*)d_k, d_centers, geom_batched, T, 0, 0);
     BIEM_LAUNCHCHK();
   }
   size_t shm = (size_t)(p->H2 + 2 * H) * sizeof(cplx) + (size_t)p->chunk_terms_max * 10 + (size_t)(p->chunk_ents_max + 1) * 4 + 16;
@@ -459,6 +469,129 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_sym(int H, int U, int
 #undef BIEM_TN_PUT
 }
 
+// ---------------------------------------------------------------------------------------------
+// Symmetric fill, systems in lanes (batches of >= 32 systems): lane = system, the wave walks the unit pairs of its chunk one
+// after the other.  Every lane of a wave then runs the SAME term list: the coefficient and the table index of a term are
+// wave-uniform (broadcast LDS reads), the pair-table row T[l][0..63] of the 64 systems is one contiguous 1-KiB load (tables
+// stored Tt[pair][l][system]), all lanes have the same trip counts (the entry-per-lane form above runs each wave to its longest
+// list: 59 % lane efficiency at n_end = 20) and no LDS gather, so no bank conflicts (58 % of its LDS cycles).  The pair tables
+// are not staged in LDS at all (they are served by L1 / L2), which also removes the H2 ceiling of the LDS budget.
+// A lane writes its 2 x 2 block into its own system's matrix: 16-byte stores 64 systems apart; consecutive unit pairs of a
+// chunk are consecutive columns, so a 128-byte line of every system fills up within a few hundred cycles and merges in L2.
+// q factors per (ball, degree, system) come transposed as well (Qt[b][n][system], k_qfactors_t).
+// ---------------------------------------------------------------------------------------------
+constexpr int FILL_SYS_THREADS = 256;
+
+__global__ void k_qfactors_t(int n_end, int B, int nb, int nbp, const cplx* __restrict__ tab, cplx* __restrict__ Qt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;            // (b, n, system), system fastest
+  if (i >= B * n_end * nbp) return;
+  // i = ((g * B + b) * n_end + n) * 64 + lane
+  const int lane = i & 63, r = i >> 6, n = r % n_end, gb = r / n_end, b = gb % B, g = gb / B;
+  const int s = g * 64 + lane, sc = s < nb ? s : nb - 1;
+  const cplx* tb = tab + ((size_t)sc * B + b) * 3 * n_end;
+  Qt[i] = cmul(tb[n], crecip(zsqrt(cmul(tb[n], tb[n_end + n]))));    // gj / sqrt(gj gh)
+}
+
+__global__ void __launch_bounds__(FILL_SYS_THREADS) k_fill_sys(int H, int U, int H2, int n_end, int B, int nb, int nbp, int npairs,
+                                                                const int* __restrict__ deg, const int* __restrict__ units,
+                                                                const int* __restrict__ spos, const int* __restrict__ schunk,
+                                                                int terms_max, int pairs_max, const uint32_t* __restrict__ qptr,
+                                                                const double* __restrict__ qcoef, const uint16_t* __restrict__ qidx,
+                                                                const cplx* __restrict__ Tt, const cplx* __restrict__ Qt,
+                                                                cplx* __restrict__ A, long long lda, long long sys_stride, int abl_nostore) {
+  extern __shared__ char smem[];
+  double* sCoef = (double*)smem;                                    // [terms_max + 1]: the chunk's terms, then a dummy (0.0, row 0)
+  uint32_t* sOff = (uint32_t*)(sCoef + terms_max + 1);              // [terms_max + 1]: row offset of the term's table entry, in elements
+  uint32_t* sPtr = sOff + terms_max + 1;                            // [4 pairs_max + 1]
+  int* sMeta = (int*)(sPtr + 4 * pairs_max + 1);                    // [3 pairs_max]: slots and degrees of the pair's units
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p0 = schunk[blockIdx.x], p1 = schunk[blockIdx.x + 1], npr = p1 - p0;
+  const uint32_t t0 = qptr[4 * (size_t)p0], t1 = qptr[4 * (size_t)p1];
+  for (uint32_t q = t0 + tid; q < t1; q += FILL_SYS_THREADS) { sCoef[q - t0] = qcoef[q]; sOff[q - t0] = (uint32_t)qidx[q] * 64u; }
+  for (int e = tid; e <= 4 * npr; e += FILL_SYS_THREADS) sPtr[e] = qptr[4 * (size_t)p0 + e] - t0;
+  if (tid == 0) { sCoef[t1 - t0] = 0.0; sOff[t1 - t0] = 0; }
+  for (int e = tid; e < npr; e += FILL_SYS_THREADS) {
+    const int pi = p0 + e, u = pi / U, v = pi - u * U;
+    const int rh = units[2 * u], rp = units[2 * u + 1], ch = units[2 * v], cp = units[2 * v + 1];
+    sMeta[3 * e] = u | ((rp != rh ? U + spos[u] : 0xffff) << 16);          // row slots: cosine, sine (0xffff: none)
+    sMeta[3 * e + 1] = v | ((cp != ch ? U + spos[v] : 0xffff) << 16);      // column slots
+    sMeta[3 * e + 2] = deg[rh] | (deg[ch] << 16);
+  }
+  __syncthreads();
+  const double q2 = 0.70710678118654752440;
+  const int ng = nbp >> 6;
+  const int ncomb = npairs * ng;
+  for (int comb = blockIdx.y; comb < ncomb; comb += gridDim.y) {
+    const int g = comb / npairs, pr = comb - g * npairs;
+    int bp = (int)((sqrtf(8.0f * (float)pr + 1.0f) + 1.0f) * 0.5f);
+    while (bp * (bp - 1) / 2 > pr) --bp;
+    while ((bp + 1) * bp / 2 <= pr) ++bp;
+    const int b = pr - bp * (bp - 1) / 2;                              // row ball b < column ball bp
+    const int sys = g * 64 + lane;
+    const bool live = sys < nb;
+    const cplx* __restrict__ Tl = Tt + ((size_t)g * npairs + pr) * H2 * 64 + lane;    // + row offset of a term
+    const cplx* __restrict__ Qr = Qt + ((size_t)g * B + b) * n_end * 64 + lane;
+    const cplx* __restrict__ Qc = Qt + ((size_t)g * B + bp) * n_end * 64 + lane;
+    cplx* As = A + (size_t)(live ? sys : 0) * sys_stride;
+    for (int e = wave; e < npr; e += FILL_SYS_THREADS / 64) {
+      const uint32_t a0 = sPtr[4 * e], a1 = sPtr[4 * e + 1], a2 = sPtr[4 * e + 2], a3 = sPtr[4 * e + 3], a4 = sPtr[4 * e + 4];
+      const uint32_t l0 = a1 - a0, l1 = a2 - a1, l2 = a3 - a2, l3 = a4 - a3;
+      uint32_t lm = l0 > l1 ? l0 : l1; lm = lm > l2 ? lm : l2; lm = lm > l3 ? lm : l3;
+      double s0r = 0, s0i = 0, s1r = 0, s1i = 0, s2r = 0, s2i = 0, s3r = 0, s3i = 0;
+      // all bounds are wave-uniform.  Per step the four chains' coefficient / offset reads are issued, then the four table loads,
+      // then the FMAs (one `if (i < len)` block per chain made hipcc wait for each load in turn: 175 ms per 256 systems);
+      // a chain that has run out takes the chunk's dummy term (coefficient 0, row 0).  Two steps per trip: eight loads in flight.
+      const uint32_t dummy = sPtr[4 * npr];
+      uint32_t q0 = a0, q1 = a1, q2p = a2, q3 = a3;
+      for (uint32_t i = 0; i < lm; i += 2) {
+        const uint32_t g0 = q0 < a1 ? q0 : dummy, g1 = q1 < a2 ? q1 : dummy, g2 = q2p < a3 ? q2p : dummy, g3 = q3 < a4 ? q3 : dummy;
+        const uint32_t h0 = q0 + 1 < a1 ? q0 + 1 : dummy, h1 = q1 + 1 < a2 ? q1 + 1 : dummy, h2 = q2p + 1 < a3 ? q2p + 1 : dummy, h3 = q3 + 1 < a4 ? q3 + 1 : dummy;
+        const double c0 = sCoef[g0], c1 = sCoef[g1], c2v = sCoef[g2], c3 = sCoef[g3];
+        const double d0 = sCoef[h0], d1 = sCoef[h1], d2v = sCoef[h2], d3 = sCoef[h3];
+        const uint32_t o0 = sOff[g0], o1 = sOff[g1], o2 = sOff[g2], o3 = sOff[g3];
+        const uint32_t r0 = sOff[h0], r1 = sOff[h1], r2o = sOff[h2], r3 = sOff[h3];
+        const cplx z0 = Tl[o0], z1 = Tl[o1], z2 = Tl[o2], z3 = Tl[o3];
+        const cplx w0 = Tl[r0], w1 = Tl[r1], w2 = Tl[r2o], w3 = Tl[r3];
+        s0r = fma(c0, z0.x, s0r); s0i = fma(c0, z0.y, s0i);
+        s1r = fma(c1, z1.x, s1r); s1i = fma(c1, z1.y, s1i);
+        s2r = fma(c2v, z2.x, s2r); s2i = fma(c2v, z2.y, s2i);
+        s3r = fma(c3, z3.x, s3r); s3i = fma(c3, z3.y, s3i);
+        s0r = fma(d0, w0.x, s0r); s0i = fma(d0, w0.y, s0i);
+        s1r = fma(d1, w1.x, s1r); s1i = fma(d1, w1.y, s1i);
+        s2r = fma(d2v, w2.x, s2r); s2i = fma(d2v, w2.y, s2i);
+        s3r = fma(d3, w3.x, s3r); s3i = fma(d3, w3.y, s3i);
+        q0 += 2; q1 += 2; q2p += 2; q3 += 2;
+      }
+      const int mr = sMeta[3 * e], mc = sMeta[3 * e + 1], md = sMeta[3 * e + 2];
+      const int row_c = mr & 0xffff, row_s = (mr >> 16) & 0xffff, col_c = mc & 0xffff, col_s = (mc >> 16) & 0xffff;
+      const bool r2 = row_s != 0xffff, c2 = col_s != 0xffff;
+      cplx x00 = make_double2(s0r, s0i), x01 = make_double2(s1r, s1i), x10 = make_double2(s2r, s2i), x11 = make_double2(s3r, s3i);
+      if (r2) {
+        const cplx a0c = make_double2((x00.x + x10.x) * q2, (x00.y + x10.y) * q2), a1c = make_double2((x01.x + x11.x) * q2, (x01.y + x11.y) * q2);
+        const cplx d0 = make_double2((x00.x - x10.x) * q2, (x00.y - x10.y) * q2), d1 = make_double2((x01.x - x11.x) * q2, (x01.y - x11.y) * q2);
+        x00 = a0c; x01 = a1c; x10 = make_double2(-d0.y, d0.x); x11 = make_double2(-d1.y, d1.x);
+      }
+      if (c2) {
+        const cplx a0c = make_double2((x00.x + x01.x) * q2, (x00.y + x01.y) * q2), d0 = make_double2((x01.x - x00.x) * q2, (x01.y - x00.y) * q2);
+        const cplx a1c = make_double2((x10.x + x11.x) * q2, (x10.y + x11.y) * q2), d1 = make_double2((x11.x - x10.x) * q2, (x11.y - x10.y) * q2);
+        x00 = a0c; x01 = make_double2(-d0.y, d0.x); x10 = a1c; x11 = make_double2(-d1.y, d1.x);
+      }
+      const cplx scale = cmul(Qr[(md & 0xffff) * 64], Qc[(md >> 16) * 64]);
+      if (live && !abl_nostore) {
+        auto put = [&](int rslot, int cslot, cplx val) {
+          const int row = b * H + rslot, col = bp * H + cslot;        // b < bp: strictly above the diagonal
+          const cplx w = cmul(val, scale);
+          As[(size_t)row * lda + col] = w;
+          if ((row >> 6) == (col >> 6)) As[(size_t)col * lda + row] = w;
+        };
+        put(row_c, col_c, x00);
+        if (c2) put(row_c, col_s, x01);
+        if (r2) { put(row_s, col_c, x10); if (c2) put(row_s, col_s, x11); }
+      }
+    }
+  }
+}
+
 // what k_fill_sym leaves: the identity diagonal blocks and the padding, again only where the factorisation reads
 // (columns c >= 64 (r / 64) of row r); one workgroup per row
 __global__ void __launch_bounds__(64) k_fill_sym_diag(int H, int N, int n_pad, cplx* __restrict__ A, long long lda, long long sys_stride) {
@@ -488,7 +621,39 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
   if (nb > 65535) { set_error("biem_fill (symmetric): at most 65535 systems per call"); return BIEM_ERR_ARG; }
   cplx* T = (cplx*)d_work;
   ProfScope ps(PK_FILL, st, (double)nb * fill_sym_bytes(n_pad));
-  if (B > 1) {
+  // Two forms.  "entry" (one unit pair per lane, pair table in LDS) is the fast one wherever its tables fit LDS; "sys" (one
+  // system per lane, pair tables from L2 / Infinity Cache: bound by the ~35-70 GB/s a CU gets from there, 150 vs 92 ms per 256
+  // systems at cfg 3) has no ceiling on the order and takes over where the entry form does not fit.  BIEM_FILL_FORM forces one.
+  const char* form = getenv("BIEM_FILL_FORM");
+  const size_t shm_entry = (size_t)(p->H2 + 2 * p->n_end) * sizeof(cplx) + (size_t)(p->qchunk_terms_max + 1) * 10 + (size_t)(4 * p->qchunk_pairs_max + 1) * 4 + 16;
+  const bool entry_fits = (int)p->qchunk.size() > 1 && shm_entry <= 160 * 1024 && p->H2 <= FILL_SYM_MAXT * FILL_SYM_THREADS;
+  const bool sys_form = form ? (form[0] == 's') : !entry_fits;
+  if (B > 1 && sys_form) {
+    // systems in lanes.  Workspace: Tt[groups][npairs][H2][64] then Qt[groups][B][n_end][64] (fill_workspace_bytes covers it)
+    const int nbp = (nb + 63) / 64 * 64, npairs = B * (B - 1) / 2;
+    const size_t need = ((size_t)npairs * p->H2 + (size_t)B * p->n_end) * nbp * sizeof(cplx);
+    if (need > work_bytes) { set_error("biem_fill (symmetric, systems in lanes): workspace too small for %d systems", nb); return BIEM_ERR_ARG; }
+    cplx* Qt = T + (size_t)npairs * p->H2 * nbp;
+    const size_t shm = (size_t)(p->schunk_terms_max + 1) * 12 + (size_t)(4 * p->schunk_pairs_max + 1) * 4 + (size_t)p->schunk_pairs_max * 12 + 16;
+    if (shm > 64 * 1024 || (size_t)p->H2 * 64 >= (1ull << 32)) { set_error("biem_fill (symmetric, systems in lanes): a unit pair of n_end=%d has %d terms", p->n_end, p->schunk_terms_max); return BIEM_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2, p->d_deg2, B,
+                       (const cplx*)d_k, d_centers, geom_batched, T, 0, nbp);
+    const int nq = B * p->n_end * nbp;
+    hipLaunchKernelGGL(k_qfactors_t, dim3((nq + 255) / 256), dim3(256), 0, st, p->n_end, B, nb, nbp, (const cplx*)d_tab, Qt);
+    BIEM_LAUNCHCHK();
+    const int nchunks = (int)p->schunk.size() - 1;
+    const long long ncomb = (long long)npairs * (nbp / 64);
+    long long gy = (16 * 256 + nchunks - 1) / nchunks;            // about 16 workgroups per CU in all, each looping over combinations
+    { const char* e = getenv("BIEM_FILL_GY"); if (e && atoi(e) > 0) gy = atoi(e); }
+    if (gy < 1) gy = 1;
+    if (gy > ncomb) gy = ncomb;
+    if (gy > 65535) gy = 65535;
+    BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_fill_sys, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(k_fill_sys, dim3(nchunks, (unsigned)gy), dim3(FILL_SYS_THREADS), shm, st, H, U, p->H2, p->n_end, B, nb, nbp, npairs, p->d_deg,
+                       p->d_units, p->d_spos, p->d_schunk, p->schunk_terms_max, p->schunk_pairs_max, p->d_qptr, p->d_qcoef, p->d_qidx16,
+                       (const cplx*)T, (const cplx*)Qt, (cplx*)d_A, lda, sys_stride, getenv("BIEM_ABL_FILL_NOSTORE") ? 1 : 0);
+    BIEM_LAUNCHCHK();
+  } else if (B > 1) {
     const int nchunks = (int)p->qchunk.size() - 1;
     const size_t shm = (size_t)(p->H2 + 2 * p->n_end) * sizeof(cplx) + (size_t)(p->qchunk_terms_max + 1) * 10 + (size_t)(4 * p->qchunk_pairs_max + 1) * 4 + 16;
     if (nchunks <= 0 || shm > 160 * 1024 || p->H2 > FILL_SYM_MAXT * FILL_SYM_THREADS) {
@@ -496,7 +661,7 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
       return BIEM_ERR_UNSUPPORTED;
     }
     hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2, p->d_deg2, B,
-                       (const cplx*)d_k, d_centers, geom_batched, T, 0);
+                       (const cplx*)d_k, d_centers, geom_batched, T, 0, 0);
     BIEM_LAUNCHCHK();
 
     const int npairs = B * (B - 1) / 2;

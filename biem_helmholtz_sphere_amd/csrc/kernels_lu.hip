@@ -1121,21 +1121,24 @@ __global__ void __launch_bounds__(256) k_back_update(const cplx* __restrict__ A,
   const int s = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const cplx* As = A + (size_t)s * sys_stride;
   cplx* Fs = F + (size_t)s * f_stride;
+  // this wave's rows of the block column: loaded once, used by the checks and by every right-hand side
+  cplx u[BACK_ROWS / 4];
+  const int i0 = row_begin + blockIdx.x * BACK_ROWS + wave * (BACK_ROWS / 4);
+#pragma unroll
+  for (int k = 0; k < BACK_ROWS / 4; ++k) u[k] = (i0 + k < row_end) ? As[(size_t)(i0 + k) * lda + jr + lane] : make_double2(0.0, 0.0);
   if (info != nullptr) {
     double um2 = 0.0;
     bool badm = false;
-    int bad_row = 0;
 #pragma unroll
     for (int k = 0; k < BACK_ROWS / 4; ++k) {
-      const int i = row_begin + blockIdx.x * BACK_ROWS + wave * (BACK_ROWS / 4) + k;
-      if (i >= row_end) break;
-      const cplx u = As[(size_t)i * lda + jr + lane], d = As[(size_t)i * lda + i];
-      const double m2 = u.x * u.x + u.y * u.y, d2 = d.x * d.x + d.y * d.y;
-      if (!(m2 <= inv_rel2 * d2)) { badm = true; bad_row = i; }
+      if (i0 + k >= row_end) break;
+      const cplx d = As[(size_t)(i0 + k) * lda + i0 + k];
+      const double m2 = u[k].x * u[k].x + u[k].y * u[k].y, d2 = d.x * d.x + d.y * d.y;
+      if (!(m2 <= inv_rel2 * d2)) badm = true;
       um2 = nan_max(um2, m2 * d2);
     }
     block_max_publish(sqrt(um2), growth + 2 * (size_t)s + 1);
-    if (badm && info[s] == 0) info[s] = -((bad_row / NB) * NB + 1);
+    if (badm && info[s] == 0) info[s] = -((i0 / NB) * NB + 1);
   }
   for (int q = 0; q < nrhs; ++q) {
     if (q > 0) __syncthreads();
@@ -1144,10 +1147,9 @@ __global__ void __launch_bounds__(256) k_back_update(const cplx* __restrict__ A,
     const cplx x = sx[lane];
 #pragma unroll
     for (int k = 0; k < BACK_ROWS / 4; ++k) {
-      const int i = row_begin + blockIdx.x * BACK_ROWS + wave * (BACK_ROWS / 4) + k;
+      const int i = i0 + k;
       if (i >= row_end) break;
-      const cplx u = As[(size_t)i * lda + jr + lane];
-      const cplx v = cmul(u, x);
+      const cplx v = cmul(u[k], x);
       double vr = v.x, vi = v.y;
       for (int o = 32; o > 0; o >>= 1) { vr += __shfl_down(vr, o, 64); vi += __shfl_down(vi, o, 64); }
       if (lane == 0) {

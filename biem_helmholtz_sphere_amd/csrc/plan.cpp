@@ -340,6 +340,22 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
       e0 = e1;
     }
     if (!fits) { p->qchunk.assign(1, 0); p->qchunk_terms_max = 0; p->qchunk_pairs_max = 0; }   // the symmetric fill reports BIEM_ERR_UNSUPPORTED
+    // small chunks of the systems-in-lanes form: at most 3072 terms (36 KB of LDS: several workgroups per CU) and 256 unit pairs
+    {
+      const long long cap = 3072, maxp = 256;
+      p->schunk.clear(); p->schunk.push_back(0);
+      p->schunk_terms_max = 0; p->schunk_pairs_max = 0;
+      long long a0 = 0;
+      while (a0 < total) {
+        long long a1 = a0 + 1;      // a single pair always fits: its four lists hold at most 4 * (2 n_end) * ... terms, checked at launch
+        while (a1 < total && a1 - a0 < maxp && (long long)(p->qptr[4 * (a1 + 1)] - p->qptr[4 * a0]) <= cap) ++a1;
+        const int nt = (int)(p->qptr[4 * a1] - p->qptr[4 * a0]);
+        if (nt > p->schunk_terms_max) p->schunk_terms_max = nt;
+        if ((int)(a1 - a0) > p->schunk_pairs_max) p->schunk_pairs_max = (int)(a1 - a0);
+        p->schunk.push_back((int)a1);
+        a0 = a1;
+      }
+    }
   }
   return BIEM_OK;
 }
@@ -375,6 +391,7 @@ int plan_upload(biem_plan* p) {
   if ((rc = up(&p->d_qcoef, p->qcoef))) return rc;
   if ((rc = up(&p->d_qidx16, p->qidx16))) return rc;
   if ((rc = up(&p->d_qchunk, p->qchunk))) return rc;
+  if ((rc = up(&p->d_schunk, p->schunk))) return rc;
   p->device = dev;
   return BIEM_OK;
 }
@@ -385,7 +402,7 @@ void plan_free(biem_plan* p) {
     (void)hipFree(p->d_W); (void)hipFree(p->d_ptr); (void)hipFree(p->d_coef); (void)hipFree(p->d_tidx);
     (void)hipFree(p->d_tidx16); (void)hipFree(p->d_chunk_ent);
     (void)hipFree(p->d_spos); (void)hipFree(p->d_hpos); (void)hipFree(p->d_qptr); (void)hipFree(p->d_qcoef); (void)hipFree(p->d_qidx16);
-    (void)hipFree(p->d_qchunk);
+    (void)hipFree(p->d_qchunk); (void)hipFree(p->d_schunk);
   }
   delete p;
 }

@@ -33,6 +33,9 @@ struct biem_plan {
   std::vector<uint16_t> qidx16;
   std::vector<int> qchunk;                  // chunks of unit pairs: [qchunk[c], qchunk[c+1]), at most FILL_SYM_THREADS pairs each
   int qchunk_terms_max = 0, qchunk_pairs_max = 0;
+  // the same lists cut into small chunks for the systems-in-lanes form of the symmetric fill (k_fill_sys: no LDS ceiling on H2)
+  std::vector<int> schunk;
+  int schunk_terms_max = 0, schunk_pairs_max = 0;
   // device mirrors (null until uploaded)
   int device = -1;
   int* d_labels = nullptr; int* d_deg = nullptr;
@@ -42,7 +45,7 @@ struct biem_plan {
   uint32_t* d_ptr = nullptr; double* d_coef = nullptr; int32_t* d_tidx = nullptr;
   uint16_t* d_tidx16 = nullptr; int* d_chunk_ent = nullptr;
   int* d_spos = nullptr; int* d_hpos = nullptr; uint32_t* d_qptr = nullptr; double* d_qcoef = nullptr; uint16_t* d_qidx16 = nullptr;
-  int* d_qchunk = nullptr;
+  int* d_qchunk = nullptr; int* d_schunk = nullptr;
 };
 
 namespace biem {

@@ -188,3 +188,41 @@ def test_beyond_the_configs_n12544_vs_oracle(amd):
     uo, _ = O.plane_wave(float(ks[1]), [1.0, 0, 0])
     ref = O.uscat(O.solve_biem("ba", centers=cen, radii=np.ones(16), k=float(ks[1]), n_end=n_end, uin=uo), pts)
     assert np.max(np.abs(ug[:, 1] - ref) / np.abs(ref)) < 1e-10
+
+
+def test_order_ceilings_of_the_fill(amd, golden_dir):
+    """Large orders.  (1) 3-D n_end = 39, the highest order the reference's 3-D goldens reach (accuracy_k_ba.csv:382-391; pair table
+    95 KB of LDS, N = 3042): golden rows at k = 1 and 8.  (2) n_end = 43: the pair table no longer fits the one-pair-per-lane form
+    (H2 = 85^2 > 7168) - the one-system-per-lane form takes over (no ceiling on the order); the solution has converged long
+    before, so it must equal the n_end = 39 golden.  (3) 2-D n_end = 152 (radial tables up to order 320; the reference's 2-D
+    goldens go on to n_end = 3444, beyond what is built here): high-wavenumber golden rows, k|t| up to 16384.
+    (4) one past the 2-D ceiling (n_end = 161): a clean error, no numbers."""
+    import csv
+    import os
+
+    from biem_helmholtz_sphere_amd import _lib as L
+
+    def run(tree, n_end, k_op):
+        c = amd.create_from_branching_types(tree)
+        d = c.c_ndim
+        e0 = np.zeros(d); e0[0] = 1.0
+        cen = O.grid_centers(0, d)
+        uin, _ = amd.plane_wave(k=_dev(1.0), direction=_dev(e0))      # incident k = 1 quirk of the golden driver (cli.py:238-244)
+        calc = amd.biem(c, centers=_dev(cen), radii=_dev(np.ones(2)), k=_dev(k_op), eta=_dev(1.0), n_end=n_end, uin=uin)
+        return complex(calc.uscat(_dev(np.zeros(d))).cpu().numpy())
+
+    rows = {}
+    with open(os.path.join(golden_dir, "accuracy_k_ba.csv")) as f:
+        for r in csv.DictReader(f):
+            rows[(r["branching_types"], int(r["n_end"]), round(float(r["k"]), 6))] = complex(r["uscat"])
+    with open(os.path.join(golden_dir, "accuracy_k_a.csv")) as f:
+        for r in csv.DictReader(f):
+            rows[("a2", int(r["n_end"]), round(float(r["k"]), 6))] = complex(r["uscat"])
+    for k in (1.0, 8.0):
+        assert abs(run("ba", 39, k) - rows[("ba", 39, k)]) < 1e-11, k
+    assert abs(run("ba", 43, 1.0) - rows[("ba", 39, 1.0)]) < 1e-11
+    for k in (8.0, 64.0, 1024.0, 4096.0):
+        got, want = run("a", 152, k), rows[("a2", 152, k)]
+        assert abs(got - want) < 1e-9 * max(1.0, abs(want)), (k, got, want)
+    with pytest.raises(L.BiemLibraryError, match="exceeds the built table size"):
+        run("a", 161, 1.0)

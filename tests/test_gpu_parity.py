@@ -879,13 +879,16 @@ def test_sharded_solve_on_rccl_world_size_one(amd):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["entry", "sys"])
 @pytest.mark.parametrize("tree,n_end,B,robin", [("a", 9, 3, False), ("ba", 6, 3, True), ("ba", 12, 2, False), ("bba", 4, 3, True), ("caa", 4, 2, False)])
-def test_symmetric_fill_vs_transformed_general_fill(amd, lib, tree, n_end, B, robin):
+def test_symmetric_fill_vs_transformed_general_fill(amd, lib, tree, n_end, B, robin, form, monkeypatch):
     """BIEM_FILL_SYMMETRIC (what the L D L^T path factors, written once by the fused kernel) against R W^H M W R^-1 formed in
     NumPy from the general BIEM_FILL_EQUILIBRATED matrix, on everything the factorisation reads (upper triangle + diagonal
-    64 x 64 tiles); the result is complex symmetric and has a unit diagonal."""
+    64 x 64 tiles); the result is complex symmetric and has a unit diagonal.  Both forms of the kernel: one unit pair per lane
+    (small batches) and one system per lane (batches of >= 32 systems; forced here on a batch of 2)."""
     from biem_helmholtz_sphere_amd import _biem as impl
 
+    monkeypatch.setenv("BIEM_FILL_FORM", form)
     l, L = lib
     d = O.tree(tree).d
     rng = np.random.default_rng(n_end + B)
@@ -903,7 +906,7 @@ def test_symmetric_fill_vs_transformed_general_fill(amd, lib, tree, n_end, B, ro
     cen_t, rad_t = _dev(cen[None]), _dev(rad[None])
     tab = torch.empty((nb, B, 3, n_end), dtype=torch.complex128, device="cuda")
     L.check(l.biem_ball_tables(plan.handle, nb, B, k_t.data_ptr(), eta_t.data_ptr(), rad_t.data_ptr(), 0, al.data_ptr(), be.data_ptr(), 0, tab.data_ptr(), None))
-    wb = l.biem_fill_workspace_bytes(plan.handle, nb, B)
+    wb = max(l.biem_fill_workspace_bytes(plan.handle, nb, B), (B * (B - 1) // 2 * plan.H2 + B * n_end) * 64 * 16)   # the forced one-system-per-lane form pads the batch to 64
     work = torch.empty(max(wb, 16), dtype=torch.uint8, device="cuda")
     M = torch.zeros((nb, npad, npad), dtype=torch.complex128, device="cuda")
     L.check(l.biem_fill(plan.handle, nb, B, k_t.data_ptr(), cen_t.data_ptr(), 0, tab.data_ptr(), L.FILL_EQUILIBRATED, M.data_ptr(), npad, npad * npad, npad, work.data_ptr(), wb, None))
