@@ -145,7 +145,7 @@ int launch_ball_tables(const biem_plan* p, int nb, int B, const double* d_k, con
 __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int H2, double Cd, const int* __restrict__ labels2,
                                                      const int* __restrict__ deg2, int B, const cplx* __restrict__ k,
                                                      const double* __restrict__ centers, int geom_batched, cplx* __restrict__ T,
-                                                     int lower, int nbp) {
+                                                     int lower, int nbp, const int* __restrict__ lin2, int H2lin) {
   __shared__ cplx sJ[kMaxRad * 2 + 6];
   __shared__ cplx sH[kMaxRad * 2 + 6];
   int pair = blockIdx.x, s = blockIdx.y;
@@ -170,7 +170,15 @@ __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int
     double re, im;
     harmonic_single(tree, labels2[3 * l], labels2[3 * l + 1], labels2[3 * l + 2], dir, &re, &im);
     int n = deg2[l];
-    out[(size_t)l * ostride] = cmul(cscale(sH[n], Cd), make_double2(re, im));
+    const cplx val = cmul(cscale(sH[n], Cd), make_double2(re, im));
+    if (lin2 == nullptr) out[(size_t)l * ostride] = val;
+    else {
+      // paired layout of the entry-per-lane symmetric fill: conjugate partners adjacent, a self-conjugate label in both places
+      cplx* o2 = T + ((size_t)s * B * B + pair) * H2lin;
+      const int i = lin2[l];
+      o2[i] = val;
+      if (labels2[3 * l + (tree == TREE_A ? 0 : tree == TREE_BA ? 1 : 2)] == 0 && (tree != TREE_CAA || labels2[3 * l + 1] == 0)) o2[i + 1] = val;
+    }
   }
 }
 
@@ -298,7 +306,7 @@ __global__ void k_fill_pad(int N, int n_pad, cplx* __restrict__ A, long long lda
 
 size_t fill_workspace_bytes(const biem_plan* p, int nb, int B) {
   // pair tables of the general / entry forms: [nb][B][B][H2]; of the systems-in-lanes form: [nb rounded up to 64][pairs][H2] + q factors
-  const size_t a = (size_t)nb * B * B * p->H2, nbp = (size_t)(nb + 63) / 64 * 64;
+  const size_t a = (size_t)nb * B * B * (p->H2lin > p->H2 ? p->H2lin : p->H2), nbp = (size_t)(nb + 63) / 64 * 64;
   const size_t b = ((size_t)(B * (B - 1) / 2) * p->H2 + (size_t)B * p->n_end) * nbp;
   return (a > b ? a : b) * sizeof(cplx);
 }
@@ -316,7 +324,7 @@ int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const doub
   ProfScope ps(PK_FILL, st, 16.0 * (double)nb * N * (double)N);
   if (B > 1) {
     hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2,
-                       p->d_deg2, B, (const cplx*)d_k, d_centers, geom_batched, T, 0, 0);
+                       p->d_deg2, B, (const cplx*)d_k, d_centers, geom_batched, T, 0, 0, nullptr, 0);
     BIEM_LAUNCHCHK();
   }
   size_t shm = (size_t)(p->H2 + 2 * H) * sizeof(cplx) + (size_t)p->chunk_terms_max * 10 + (size_t)(p->chunk_ents_max + 1) * 4 + 16;
@@ -351,8 +359,8 @@ int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const doub
 // registers during the previous combination's contraction - so the term lists are read from L2 once per workgroup.
 // Each thread runs the four independent chains of its 2 x 2 block (the per-term chain idx -> T -> fma is LDS-latency bound).
 // ---------------------------------------------------------------------------------------------
-constexpr int FILL_SYM_THREADS = 512;
-constexpr int FILL_SYM_MAXT = 14;          // pair-table elements prefetched per thread: H2 <= 14 * 512
+constexpr int FILL_SYM_THREADS = 1024;
+constexpr int FILL_SYM_MAXT = 8;           // pair-table elements prefetched per thread: H2lin <= 8 * 1024
 
 // KT = pair-table elements each thread carries in registers from one combination to the next (KT * 512 >= H2); the loads are
 // unconditional with a clamped index (a conditionally assigned register array was kept in scratch by hipcc)
@@ -368,13 +376,13 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_sym(int H, int U, int
   cplx* sT = (cplx*)smem;                                  // [H2] pair table of the current combination
   cplx* sQ = sT + H2;                                      // [2][n_end]: q of the row ball, q of the column ball
   double* sCoef = (double*)(sQ + 2 * n_end);               // [terms_max + 1]: the chunk's terms, then a dummy (0.0, index 0)
-  uint32_t* sPtr = (uint32_t*)(sCoef + terms_max + 1);     // [4 pairs_max + 1], relative to the chunk's first term
-  uint16_t* sIdx = (uint16_t*)(sPtr + 4 * pairs_max + 1);  // [terms_max + 1]
+  uint32_t* sPtr = (uint32_t*)(sCoef + terms_max + 1);     // [2 pairs_max + 1], relative to the chunk's first term
+  uint16_t* sIdx = (uint16_t*)(sPtr + 2 * pairs_max + 1);  // [terms_max + 1]
   const int tid = threadIdx.x;
   const int p0 = qchunk[blockIdx.x], p1 = qchunk[blockIdx.x + 1], npr = p1 - p0;
-  const uint32_t t0 = qptr[4 * (size_t)p0], t1 = qptr[4 * (size_t)p1];
+  const uint32_t t0 = qptr[2 * (size_t)p0], t1 = qptr[2 * (size_t)p1];
   for (uint32_t q = t0 + tid; q < t1; q += FILL_SYM_THREADS) { sCoef[q - t0] = qcoef[q]; sIdx[q - t0] = qidx[q]; }
-  for (int e = tid; e <= 4 * npr; e += FILL_SYM_THREADS) sPtr[e] = qptr[4 * (size_t)p0 + e] - t0;
+  for (int e = tid; e <= 2 * npr; e += FILL_SYM_THREADS) sPtr[e] = qptr[2 * (size_t)p0 + e] - t0;
   if (tid == 0) { sCoef[t1 - t0] = 0.0; sIdx[t1 - t0] = 0; }
   // this thread's unit pair (fixed for the whole kernel)
   const bool active = tid < npr;
@@ -386,9 +394,9 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_sym(int H, int U, int
   const int nrow = deg[rh], ncol = deg[ch];
   const double q2 = 0.70710678118654752440;
   const int ncomb = npairs * nb;
-  // fourteen named registers instead of an array: hipcc kept every array form (plain, unrolled, compile-time indexed through
+  // eight named registers instead of an array: hipcc kept every array form (plain, unrolled, compile-time indexed through
   // lambdas) in scratch memory
-#define BIEM_TN_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
+#define BIEM_TN_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 #define BIEM_TN_DECL(k) cplx tn##k = make_double2(0.0, 0.0);
   BIEM_TN_LIST(BIEM_TN_DECL)
 #define BIEM_TN_LOAD(k) if (k < KT) { const int l = k * FILL_SYM_THREADS + tid; tn##k = Tp_[l < H2 ? l : H2 - 1]; }
@@ -419,28 +427,31 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_sym(int H, int U, int
     __syncthreads();
     if (comb + (int)gridDim.y < ncomb) { const cplx* Tp_ = table_of(comb + (int)gridDim.y); BIEM_TN_LIST(BIEM_TN_LOAD) }   // lands while this combination is contracted
     if (!active) continue;
-    // the four chains of the 2 x 2 block advance together: per step all coefficient / index reads are issued, then the four
-    // table reads, then the FMAs (with one `if (i < len)` block per chain hipcc waited for every chain's LDS reads in turn:
-    // 70 % of the wave cycles were waits).  A chain that has run out reads the chunk's dummy term (coefficient 0, index 0).
-    const uint32_t dummy = sPtr[4 * npr];                 // = number of terms of the chunk: the slot behind them
-    uint32_t q0 = sPtr[4 * tid], q1 = sPtr[4 * tid + 1], q2p = sPtr[4 * tid + 2], q3 = sPtr[4 * tid + 3];
-    const uint32_t e0 = q1, e1 = q2p, e2 = q3, e3 = sPtr[4 * tid + 4];
-    uint32_t lm = e0 - q0;
-    lm = (e1 - q1) > lm ? (e1 - q1) : lm; lm = (e2 - q2p) > lm ? (e2 - q2p) : lm; lm = (e3 - q3) > lm ? (e3 - q3) : lm;
-    double s0r = 0, s0i = 0, s1r = 0, s1i = 0, s2r = 0, s2i = 0, s3r = 0, s3i = 0;
+    // Two term lists per unit pair (plan.hpp): A = (h,h'), B = (h,p'); the conjugate entries (p,p') and (p,h') have the same
+    // coefficients with every table index replaced by its partner's, which the paired table layout keeps at index ^ 1.  So one
+    // coefficient and one index read feed two chains; per step all reads of both lists are issued, then the four table reads,
+    // then the FMAs.  A list that has run out reads the chunk's dummy term (coefficient 0, index 0).
+    const uint32_t dummy = sPtr[2 * npr];                 // = number of terms of the chunk: the slot behind them
+    uint32_t qa = sPtr[2 * tid], qb = sPtr[2 * tid + 1];
+    const uint32_t ea = qb, eb = sPtr[2 * tid + 2];
+    const uint32_t lm = (ea - qa) > (eb - qb) ? (ea - qa) : (eb - qb);
+    double s0r = 0, s0i = 0, s1r = 0, s1i = 0, s2r = 0, s2i = 0, s3r = 0, s3i = 0;      // A, mirror of A, B, mirror of B
     for (uint32_t i = 0; i < lm; ++i) {
-      const uint32_t g0 = q0 < e0 ? q0 : dummy, g1 = q1 < e1 ? q1 : dummy, g2 = q2p < e2 ? q2p : dummy, g3 = q3 < e3 ? q3 : dummy;
-      const double c0 = sCoef[g0], c1 = sCoef[g1], c2v = sCoef[g2], c3 = sCoef[g3];
-      const unsigned i0 = sIdx[g0], i1 = sIdx[g1], i2 = sIdx[g2], i3 = sIdx[g3];
-      const cplx z0 = sT[i0], z1 = sT[i1], z2 = sT[i2], z3 = sT[i3];
-      s0r = fma(c0, z0.x, s0r); s0i = fma(c0, z0.y, s0i);
-      s1r = fma(c1, z1.x, s1r); s1i = fma(c1, z1.y, s1i);
-      s2r = fma(c2v, z2.x, s2r); s2i = fma(c2v, z2.y, s2i);
-      s3r = fma(c3, z3.x, s3r); s3i = fma(c3, z3.y, s3i);
-      ++q0; ++q1; ++q2p; ++q3;
+      const uint32_t ga = qa < ea ? qa : dummy, gb = qb < eb ? qb : dummy;
+      const double ca = sCoef[ga], cb = sCoef[gb];
+      const unsigned ia = sIdx[ga], ib = sIdx[gb];
+      const cplx za = sT[ia], zam = sT[ia ^ 1u], zb = sT[ib], zbm = sT[ib ^ 1u];
+      s0r = fma(ca, za.x, s0r); s0i = fma(ca, za.y, s0i);
+      s1r = fma(ca, zam.x, s1r); s1i = fma(ca, zam.y, s1i);
+      s2r = fma(cb, zb.x, s2r); s2i = fma(cb, zb.y, s2i);
+      s3r = fma(cb, zbm.x, s3r); s3i = fma(cb, zbm.y, s3i);
+      ++qa; ++qb;
     }
     // W^H S W on the 2 x 2 block: rows (h + p)/sqrt2, i (h - p)/sqrt2; columns (h' + p')/sqrt2, i (p' - h')/sqrt2
-    cplx x00 = make_double2(s0r, s0i), x01 = make_double2(s1r, s1i), x10 = make_double2(s2r, s2i), x11 = make_double2(s3r, s3i);
+    // raw entries: (h,h') = A; (p,p') = mirror A and (h,p') = B, (p,h') = mirror B when both units are doubles; with a single
+    // row unit the mirror of A is (h,p'), with a single column unit it is (p,h')
+    const cplx mA = make_double2(s1r, s1i);
+    cplx x00 = make_double2(s0r, s0i), x01 = (r2 && c2) ? make_double2(s2r, s2i) : mA, x10 = (r2 && c2) ? make_double2(s3r, s3i) : mA, x11 = mA;
     if (r2) {
       const cplx a0c = make_double2((x00.x + x10.x) * q2, (x00.y + x10.y) * q2), a1c = make_double2((x01.x + x11.x) * q2, (x01.y + x11.y) * q2);
       const cplx d0 = make_double2((x00.x - x10.x) * q2, (x00.y - x10.y) * q2), d1 = make_double2((x01.x - x11.x) * q2, (x01.y - x11.y) * q2);
@@ -625,8 +636,8 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
   // system per lane, pair tables from L2 / Infinity Cache: bound by the ~35-70 GB/s a CU gets from there, 150 vs 92 ms per 256
   // systems at cfg 3) has no ceiling on the order and takes over where the entry form does not fit.  BIEM_FILL_FORM forces one.
   const char* form = getenv("BIEM_FILL_FORM");
-  const size_t shm_entry = (size_t)(p->H2 + 2 * p->n_end) * sizeof(cplx) + (size_t)(p->qchunk_terms_max + 1) * 10 + (size_t)(4 * p->qchunk_pairs_max + 1) * 4 + 16;
-  const bool entry_fits = (int)p->qchunk.size() > 1 && shm_entry <= 160 * 1024 && p->H2 <= FILL_SYM_MAXT * FILL_SYM_THREADS;
+  const size_t shm_entry = (size_t)(p->H2lin + 2 * p->n_end) * sizeof(cplx) + (size_t)(p->qchunk_terms_max + 1) * 10 + (size_t)(2 * p->qchunk_pairs_max + 1) * 4 + 16;
+  const bool entry_fits = p->pair_lists_ok && (int)p->qchunk.size() > 1 && shm_entry <= 160 * 1024 && p->H2lin <= FILL_SYM_MAXT * FILL_SYM_THREADS;
   const bool sys_form = form ? (form[0] == 's') : !entry_fits;
   if (B > 1 && sys_form) {
     // systems in lanes.  Workspace: Tt[groups][npairs][H2][64] then Qt[groups][B][n_end][64] (fill_workspace_bytes covers it)
@@ -637,7 +648,7 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
     const size_t shm = (size_t)(p->schunk_terms_max + 1) * 12 + (size_t)(4 * p->schunk_pairs_max + 1) * 4 + (size_t)p->schunk_pairs_max * 12 + 16;
     if (shm > 64 * 1024 || (size_t)p->H2 * 64 >= (1ull << 32)) { set_error("biem_fill (symmetric, systems in lanes): a unit pair of n_end=%d has %d terms", p->n_end, p->schunk_terms_max); return BIEM_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2, p->d_deg2, B,
-                       (const cplx*)d_k, d_centers, geom_batched, T, 0, nbp);
+                       (const cplx*)d_k, d_centers, geom_batched, T, 0, nbp, nullptr, 0);
     const int nq = B * p->n_end * nbp;
     hipLaunchKernelGGL(k_qfactors_t, dim3((nq + 255) / 256), dim3(256), 0, st, p->n_end, B, nb, nbp, (const cplx*)d_tab, Qt);
     BIEM_LAUNCHCHK();
@@ -655,15 +666,14 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
     BIEM_LAUNCHCHK();
   } else if (B > 1) {
     const int nchunks = (int)p->qchunk.size() - 1;
-    const size_t shm = (size_t)(p->H2 + 2 * p->n_end) * sizeof(cplx) + (size_t)(p->qchunk_terms_max + 1) * 10 + (size_t)(4 * p->qchunk_pairs_max + 1) * 4 + 16;
-    if (nchunks <= 0 || shm > 160 * 1024 || p->H2 > FILL_SYM_MAXT * FILL_SYM_THREADS) {
-      set_error("biem_fill (symmetric): tables do not fit LDS (n_end=%d: H2=%d, chunk terms=%d)", p->n_end, p->H2, p->qchunk_terms_max);
+    const size_t shm = shm_entry;
+    if (!entry_fits) {
+      set_error("biem_fill (symmetric, one unit pair per lane): tables do not fit LDS (n_end=%d: H2=%d, chunk terms=%d)", p->n_end, p->H2, p->qchunk_terms_max);
       return BIEM_ERR_UNSUPPORTED;
     }
     hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2, p->d_deg2, B,
-                       (const cplx*)d_k, d_centers, geom_batched, T, 0, 0);
+                       (const cplx*)d_k, d_centers, geom_batched, T, 0, 0, p->d_lin2, p->H2lin);
     BIEM_LAUNCHCHK();
-
     const int npairs = B * (B - 1) / 2;
     const long long ncomb = (long long)npairs * nb;
     // enough workgroups to fill the chip a few times over, each with a long loop over combinations
@@ -671,22 +681,20 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
     if (gy < 1) gy = 1;
     if (gy > ncomb) gy = ncomb;
     if (gy > 65535) gy = 65535;
-    const int kt_need = (p->H2 + FILL_SYM_THREADS - 1) / FILL_SYM_THREADS;
+    const int kt_need = (p->H2lin + FILL_SYM_THREADS - 1) / FILL_SYM_THREADS;
 #define BIEM_LAUNCH_FILL_SYM(KT)                                                                                                          \
   {                                                                                                                                       \
     BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_fill_sym<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                  \
-    hipLaunchKernelGGL(k_fill_sym<KT>, dim3(nchunks, (unsigned)gy), dim3(FILL_SYM_THREADS), shm, st, H, U, p->H2, p->n_end, B, nb, npairs, \
-                       p->d_deg, p->d_units, p->d_spos, p->d_qchunk, p->qchunk_terms_max, p->qchunk_pairs_max, p->d_qptr, p->d_qcoef,     \
-                       p->d_qidx16, T, (const cplx*)d_tab, (cplx*)d_A, lda, sys_stride);                                                  \
+    hipLaunchKernelGGL(k_fill_sym<KT>, dim3(nchunks, (unsigned)gy), dim3(FILL_SYM_THREADS), shm, st, H, U, p->H2lin, p->n_end, B, nb, npairs, \
+                       p->d_deg, p->d_units, p->d_spos, p->d_qchunk, p->qchunk_terms_max, p->qchunk_pairs_max, p->d_q2ptr, p->d_q2coef,   \
+                       p->d_q2idx16, T, (const cplx*)d_tab, (cplx*)d_A, lda, sys_stride);                                                 \
   }
     if (kt_need <= 1) BIEM_LAUNCH_FILL_SYM(1)
     else if (kt_need <= 2) BIEM_LAUNCH_FILL_SYM(2)
     else if (kt_need <= 3) BIEM_LAUNCH_FILL_SYM(3)
     else if (kt_need <= 4) BIEM_LAUNCH_FILL_SYM(4)
     else if (kt_need <= 6) BIEM_LAUNCH_FILL_SYM(6)
-    else if (kt_need <= 8) BIEM_LAUNCH_FILL_SYM(8)
-    else if (kt_need <= 11) BIEM_LAUNCH_FILL_SYM(11)
-    else BIEM_LAUNCH_FILL_SYM(14)
+    else BIEM_LAUNCH_FILL_SYM(8)
 #undef BIEM_LAUNCH_FILL_SYM
     BIEM_LAUNCHCHK();
   }

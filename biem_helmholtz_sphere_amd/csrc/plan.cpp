@@ -320,26 +320,75 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
           p->qptr[((size_t)u * U + v) * 4 + slot + 1] = (uint32_t)p->qcoef.size();
         }
       }
-    // chunks: the pair table (H2 complex), the per-degree factors of two balls, the slot pointers and the term slice share LDS
-    const int max_pairs = 512;                                     // = FILL_SYM_THREADS: one unit pair per thread
-    const long long budget = 158 * 1024 - (long long)p->H2 * 16 - (long long)2 * n_end * 16 - (long long)(4 * max_pairs + 1) * 4 - 64;
+    // ---- the two-list form of the entry-per-lane kernel ----
+    {
+      std::map<std::tuple<int, int, int>, int> pos2;
+      const int H2 = p->H2;
+      for (int l = 0; l < H2; ++l) pos2[std::make_tuple(p->labels2[3 * l], p->labels2[3 * l + 1], p->labels2[3 * l + 2])] = l;
+      std::vector<int> partner2(H2, -1);
+      bool ok = true;
+      for (int l = 0; l < H2 && ok; ++l) {
+        int a = p->labels2[3 * l], b = p->labels2[3 * l + 1], c = p->labels2[3 * l + 2];
+        if (tree == TREE_A) a = -a; else if (tree == TREE_BA) b = -b; else if (tree == TREE_BBA) c = -c; else { b = -b; c = -c; }
+        auto it = pos2.find(std::make_tuple(a, b, c));
+        if (it == pos2.end()) ok = false; else partner2[l] = it->second;
+      }
+      p->lin2.assign(H2, 0);
+      int ne = 0;
+      for (int l = 0; l < H2 && ok; ++l)
+        if (l <= partner2[l]) { p->lin2[l] = 2 * ne; if (partner2[l] != l) p->lin2[partner2[l]] = 2 * ne + 1; ++ne; }
+      p->H2lin = 2 * ne;
+      if (p->H2lin > 65535) ok = false;
+      p->q2ptr.assign((size_t)2 * U * U + 1, 0);
+      p->q2coef.clear(); p->q2idx16.clear();
+      auto same_mirrored = [&](size_t ea, size_t eb) {      // list of entry eb == list of entry ea with partner indices?
+        if (p->ptr[ea + 1] - p->ptr[ea] != p->ptr[eb + 1] - p->ptr[eb]) return false;
+        for (uint32_t q = p->ptr[ea], r = p->ptr[eb]; q < p->ptr[ea + 1]; ++q, ++r) {
+          if (fabs(p->coef[q] - p->coef[r]) > 1e-13 * (fabs(p->coef[q]) + 1e-300)) return false;
+          if (partner2[p->tidx[q]] != p->tidx[r]) return false;
+        }
+        return true;
+      };
+      for (int u = 0; u < U && ok; ++u)
+        for (int v = 0; v < U && ok; ++v) {
+          const int h = p->units[2 * u], pp = p->units[2 * u + 1], ch = p->units[2 * v], cp = p->units[2 * v + 1];
+          const bool r2 = pp != h, c2 = cp != ch;
+          const size_t eA = (size_t)h * H + ch;
+          for (uint32_t q = p->ptr[eA]; q < p->ptr[eA + 1]; ++q) { p->q2coef.push_back(p->coef[q]); p->q2idx16.push_back((uint16_t)p->lin2[p->tidx[q]]); }
+          p->q2ptr[((size_t)u * U + v) * 2 + 1] = (uint32_t)p->q2coef.size();
+          // the mirror of list A: (p,p') when both units are doubles, (p,h') when only the row unit is, (h,p') when only the column unit is
+          if (r2 && c2) ok = ok && same_mirrored(eA, (size_t)pp * H + cp);
+          else if (r2) ok = ok && same_mirrored(eA, (size_t)pp * H + ch);
+          else if (c2) ok = ok && same_mirrored(eA, (size_t)h * H + cp);
+          if (r2 && c2) {
+            const size_t eB = (size_t)h * H + cp;
+            for (uint32_t q = p->ptr[eB]; q < p->ptr[eB + 1]; ++q) { p->q2coef.push_back(p->coef[q]); p->q2idx16.push_back((uint16_t)p->lin2[p->tidx[q]]); }
+            ok = ok && same_mirrored(eB, (size_t)pp * H + ch);
+          }
+          p->q2ptr[((size_t)u * U + v) * 2 + 2] = (uint32_t)p->q2coef.size();
+        }
+      p->pair_lists_ok = ok;
+    }
+    // chunks: the paired pair table (H2lin complex), the per-degree factors of two balls, the list pointers and the term slice share LDS
+    const int max_pairs = 1024;                                    // = FILL_SYM_THREADS: one unit pair per thread
+    const long long budget = 158 * 1024 - (long long)p->H2lin * 16 - (long long)2 * n_end * 16 - (long long)(2 * max_pairs + 1) * 4 - 64;
     long long cap_terms = budget > 0 ? budget / 10 : 0;
     const long long total = (long long)U * U;
     p->qchunk.clear(); p->qchunk.push_back(0);
     p->qchunk_terms_max = 0; p->qchunk_pairs_max = 0;
     long long e0 = 0;
-    bool fits = cap_terms > 0;
+    bool fits = cap_terms > 0 && p->pair_lists_ok;
     while (fits && e0 < total) {
       long long e1 = e0 + 1;
-      if ((long long)(p->qptr[4 * e1] - p->qptr[4 * e0]) > cap_terms) { fits = false; break; }     // one pair alone exceeds the budget
-      while (e1 < total && e1 - e0 < max_pairs && (long long)(p->qptr[4 * (e1 + 1)] - p->qptr[4 * e0]) <= cap_terms) ++e1;
-      const int nt = (int)(p->qptr[4 * e1] - p->qptr[4 * e0]);
+      if ((long long)(p->q2ptr[2 * e1] - p->q2ptr[2 * e0]) > cap_terms) { fits = false; break; }     // one pair alone exceeds the budget
+      while (e1 < total && e1 - e0 < max_pairs && (long long)(p->q2ptr[2 * (e1 + 1)] - p->q2ptr[2 * e0]) <= cap_terms) ++e1;
+      const int nt = (int)(p->q2ptr[2 * e1] - p->q2ptr[2 * e0]);
       if (nt > p->qchunk_terms_max) p->qchunk_terms_max = nt;
       if ((int)(e1 - e0) > p->qchunk_pairs_max) p->qchunk_pairs_max = (int)(e1 - e0);
       p->qchunk.push_back((int)e1);
       e0 = e1;
     }
-    if (!fits) { p->qchunk.assign(1, 0); p->qchunk_terms_max = 0; p->qchunk_pairs_max = 0; }   // the symmetric fill reports BIEM_ERR_UNSUPPORTED
+    if (!fits) { p->qchunk.assign(1, 0); p->qchunk_terms_max = 0; p->qchunk_pairs_max = 0; }   // the systems-in-lanes form takes over
     // small chunks of the systems-in-lanes form: at most 3072 terms (36 KB of LDS: several workgroups per CU) and 256 unit pairs
     {
       const long long cap = 3072, maxp = 256;
@@ -392,6 +441,10 @@ int plan_upload(biem_plan* p) {
   if ((rc = up(&p->d_qidx16, p->qidx16))) return rc;
   if ((rc = up(&p->d_qchunk, p->qchunk))) return rc;
   if ((rc = up(&p->d_schunk, p->schunk))) return rc;
+  if ((rc = up(&p->d_lin2, p->lin2))) return rc;
+  if ((rc = up(&p->d_q2ptr, p->q2ptr))) return rc;
+  if ((rc = up(&p->d_q2coef, p->q2coef))) return rc;
+  if ((rc = up(&p->d_q2idx16, p->q2idx16))) return rc;
   p->device = dev;
   return BIEM_OK;
 }
@@ -403,6 +456,7 @@ void plan_free(biem_plan* p) {
     (void)hipFree(p->d_tidx16); (void)hipFree(p->d_chunk_ent);
     (void)hipFree(p->d_spos); (void)hipFree(p->d_hpos); (void)hipFree(p->d_qptr); (void)hipFree(p->d_qcoef); (void)hipFree(p->d_qidx16);
     (void)hipFree(p->d_qchunk); (void)hipFree(p->d_schunk);
+    (void)hipFree(p->d_lin2); (void)hipFree(p->d_q2ptr); (void)hipFree(p->d_q2coef); (void)hipFree(p->d_q2idx16);
   }
   delete p;
 }

@@ -31,6 +31,16 @@ struct biem_plan {
   std::vector<uint32_t> qptr;               // [4 U U + 1]
   std::vector<double> qcoef;
   std::vector<uint16_t> qidx16;
+  // entry-per-lane form: conjugation pairs the lists - (p,p') has the coefficients of (h,h') with every table index replaced by
+  // its conjugate partner's, (p,h') those of (h,p') - so a unit pair carries TWO lists (A: (h,h'), B: (h,p'), B only when both units
+  // are doubles) and the pair table is stored with partners adjacent: lin2[l] = 2e for the first member of unit e of the degree
+  // < 2 n_end - 1 labels, 2e + 1 for its partner (a self-conjugate label fills both), so the partner's entry is index ^ 1.
+  std::vector<int> lin2;                    // [H2]
+  int H2lin = 0;                            // 2 * (number of units among the H2 labels)
+  bool pair_lists_ok = false;               // the pairing was verified on every unit pair of this plan
+  std::vector<uint32_t> q2ptr;              // [2 U U + 1]
+  std::vector<double> q2coef;
+  std::vector<uint16_t> q2idx16;            // indices into the paired table layout
   std::vector<int> qchunk;                  // chunks of unit pairs: [qchunk[c], qchunk[c+1]), at most FILL_SYM_THREADS pairs each
   int qchunk_terms_max = 0, qchunk_pairs_max = 0;
   // the same lists cut into small chunks for the systems-in-lanes form of the symmetric fill (k_fill_sys: no LDS ceiling on H2)
@@ -46,6 +56,7 @@ struct biem_plan {
   uint16_t* d_tidx16 = nullptr; int* d_chunk_ent = nullptr;
   int* d_spos = nullptr; int* d_hpos = nullptr; uint32_t* d_qptr = nullptr; double* d_qcoef = nullptr; uint16_t* d_qidx16 = nullptr;
   int* d_qchunk = nullptr; int* d_schunk = nullptr;
+  int* d_lin2 = nullptr; uint32_t* d_q2ptr = nullptr; double* d_q2coef = nullptr; uint16_t* d_q2idx16 = nullptr;
 };
 
 namespace biem {
