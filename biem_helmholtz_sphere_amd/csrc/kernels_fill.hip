@@ -166,19 +166,50 @@ __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int
   // workgroup of a fill - they all work on the same group at a time - hits the same quarter of the L2 channels)
   cplx* out = nbp > 0 ? T + (((size_t)(s >> 6) * (B * (B - 1) / 2) + (bp * (bp - 1) / 2 + b)) * H2) * 64 + (s & 63) : T + ((size_t)s * B * B + pair) * H2;
   const size_t ostride = nbp > 0 ? 64 : 1;
+  auto emit = [&](int l, cplx val, bool self_conjugate) {
+    if (lin2 == nullptr) { out[(size_t)l * ostride] = val; return; }
+    // paired layout of the entry-per-lane symmetric fill: conjugate partners adjacent, a self-conjugate label in both places
+    cplx* o2 = T + ((size_t)s * B * B + pair) * H2lin;
+    const int i = lin2[l];
+    o2[i] = val;
+    if (self_conjugate) o2[i + 1] = val;
+  };
+  if (tree == TREE_BA) {
+    // d = 3: one lane per order |m| runs the degree recurrence of Pbar_n^m ONCE (n = m .. n2-1) and writes both signs; evaluating
+    // every label from scratch (generic branch below) repeats that recurrence, square roots and divisions included, per label:
+    // 10 ms per 256 systems of cfg 3 against the fill's 47
+    for (int m = threadIdx.x; m < n2; m += 64) {
+      double sn, cs;
+      sincos((double)m * dir.phi, &sn, &cs);
+      double pmm = 0.70710678118654752440;
+      for (int i = 1; i <= m; ++i) pmm *= sqrt((double)(2 * i + 1) / (double)(2 * i)) * dir.s0;
+      double p0 = 0.0, p1 = pmm;
+      for (int n = m; n < n2; ++n) {
+        if (n > m) {
+          double p2;
+          if (n == m + 1) p2 = sqrt((double)(2 * m + 3)) * dir.c0 * pmm;
+          else {
+            const double a = sqrt((double)(4 * n * n - 1) / (double)(n * n - m * m));
+            const double bq = sqrt((double)((n - 1) * (n - 1) - m * m) / (double)(4 * (n - 1) * (n - 1) - 1));
+            p2 = a * (dir.c0 * p1 - bq * p0);
+          }
+          p0 = p1; p1 = p2;
+        }
+        const double amp = p1 * kInvSqrt2Pi;
+        const cplx h = cscale(sH[n], Cd);
+        const int l0 = n * n + n;
+        emit(l0 + m, cmul(h, make_double2(amp * cs, amp * sn)), m == 0);
+        if (m > 0) emit(l0 - m, cmul(h, make_double2(amp * cs, -amp * sn)), false);
+      }
+    }
+    return;
+  }
   for (int l = threadIdx.x; l < H2; l += 64) {
     double re, im;
     harmonic_single(tree, labels2[3 * l], labels2[3 * l + 1], labels2[3 * l + 2], dir, &re, &im);
     int n = deg2[l];
     const cplx val = cmul(cscale(sH[n], Cd), make_double2(re, im));
-    if (lin2 == nullptr) out[(size_t)l * ostride] = val;
-    else {
-      // paired layout of the entry-per-lane symmetric fill: conjugate partners adjacent, a self-conjugate label in both places
-      cplx* o2 = T + ((size_t)s * B * B + pair) * H2lin;
-      const int i = lin2[l];
-      o2[i] = val;
-      if (labels2[3 * l + (tree == TREE_A ? 0 : tree == TREE_BA ? 1 : 2)] == 0 && (tree != TREE_CAA || labels2[3 * l + 1] == 0)) o2[i + 1] = val;
-    }
+    emit(l, val, labels2[3 * l + (tree == TREE_A ? 0 : 2)] == 0 && (tree != TREE_CAA || labels2[3 * l + 1] == 0));
   }
 }
 

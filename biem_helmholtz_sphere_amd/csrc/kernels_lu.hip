@@ -1643,6 +1643,104 @@ __global__ void __launch_bounds__(256) k_diag_utu(cplx* __restrict__ A, long lon
   if (tid == 0 && bad && info[s] == 0) info[s] = -(j + 1);
 }
 
+// Back substitution of the row form, one launch per 64-row block (bottom up), one 1024-thread workgroup per system:
+//   y_R -= U[R, C] x_C over all solved columns C right of the block - the 16 waves stream 4 rows each across the strip, 64 columns
+//   per step, partial sums per lane and ONE reduction per row at the end - then the 64 x 64 triangular solve U[R,R] x_R = y_R in
+//   the same launch (diagonal block in LDS, one wave).  Reads U exactly once in long contiguous runs (the column-block form
+//   k_back_update re-launches per 64 columns with 16-KiB workgroups: 31 vs 84 GB / 5 TB/s = 17 ms per 256 systems at cfg 3).
+// The pass also takes the checks of the strip entries (see k_back_update).  NQ right-hand sides per pass.
+template <int NQ>
+__global__ void __launch_bounds__(1024) k_back_row(const cplx* __restrict__ A, long long lda, long long sys_stride, cplx* __restrict__ Y,
+                                                    int nrhs, int n_pad, int q0, int nq, int ib, int do_checks,
+                                                    int* __restrict__ info, unsigned long long* __restrict__ growth, double inv_rel2) {
+  // Y[s][q][row]: the right-hand sides / solutions in a compact copy (in the augmented matrix they sit one row stride apart:
+  // gathering 64 of them per step from there cost more than the four 1-KiB row loads they are multiplied with)
+  __shared__ cplx sU[NB][NB + 1];
+  __shared__ cplx sy[NB][NQ];
+  __shared__ double sm_max2[16];
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const cplx* As = A + (size_t)s * sys_stride;
+  cplx* Ys = Y + (size_t)s * nrhs * n_pad;
+  const int rb = ib * NB;
+  for (int e = tid; e < NB * NB; e += 1024) { const int r = e >> 6, c = e & 63; sU[r][c] = As[(size_t)(rb + r) * lda + rb + c]; }
+  cplx acc[4][NQ];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[k][q] = make_double2(0.0, 0.0);
+  double d2[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const cplx d = As[(size_t)(rb + 4 * wave + k) * lda + rb + 4 * wave + k]; d2[k] = d.x * d.x + d.y * d.y; }
+  double um2 = 0.0;
+  bool badm = false;
+  const cplx* Ur = As + (size_t)(rb + 4 * wave) * lda + lane;
+#pragma unroll 2
+  for (int c0 = rb + NB; c0 < n_pad; c0 += NB) {
+    cplx x[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) x[q] = q < nq ? Ys[(size_t)(q0 + q) * n_pad + c0 + lane] : make_double2(0.0, 0.0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const cplx u = Ur[(size_t)k * lda + c0];
+      if (do_checks) {
+        const double m2 = u.x * u.x + u.y * u.y;
+        if (!(m2 <= inv_rel2 * d2[k])) badm = true;
+        um2 = nan_max(um2, m2 * d2[k]);
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) acc[k][q] = cfma(u, x[q], acc[k][q]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      double vr = acc[k][q].x, vi = acc[k][q].y;
+      for (int o = 32; o > 0; o >>= 1) { vr += __shfl_down(vr, o, 64); vi += __shfl_down(vi, o, 64); }
+      if (lane == 0) {
+        cplx y = q < nq ? Ys[(size_t)(q0 + q) * n_pad + rb + 4 * wave + k] : make_double2(0.0, 0.0);
+        y.x -= vr; y.y -= vi;
+        sy[4 * wave + k][q] = y;
+      }
+    }
+  if (do_checks) {
+    double m = sqrt(um2);
+    for (int o = 32; o > 0; o >>= 1) m = nan_max(m, __shfl_down(m, o, 64));
+    if (lane == 0) sm_max2[wave] = m;
+    if (badm && info[s] == 0) info[s] = -(rb + 1);
+  }
+  __syncthreads();
+  if (do_checks && tid == 0) {
+    double m = sm_max2[0];
+    for (int w = 1; w < 16; ++w) m = nan_max(m, sm_max2[w]);
+    unsigned long long* dst = growth + 2 * (size_t)s + 1;
+    if (!(m <= __longlong_as_double((long long)*(volatile unsigned long long*)dst))) atomicMax(dst, (unsigned long long)__double_as_longlong(m));
+  }
+  if (wave == 0) {            // the triangular solve of the block: lane = row, wave-synchronous
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (q >= nq) break;
+      cplx y = sy[lane][q];
+      for (int c = NB - 1; c >= 0; --c) {
+        if (lane == c) y = cmul(y, crecip(sU[c][c]));
+        const double xr = __shfl(y.x, c, 64), xi = __shfl(y.y, c, 64);
+        if (lane < c) y = cfnma(sU[lane][c], make_double2(xr, xi), y);
+      }
+      Ys[(size_t)(q0 + q) * n_pad + rb + lane] = y;
+    }
+  }
+}
+
+// right-hand-side columns of the augmented matrix <-> compact Y[s][q][row]
+__global__ void __launch_bounds__(256) k_rhs_compact(cplx* __restrict__ A, long long lda, long long sys_stride, cplx* __restrict__ Y, int nrhs,
+                                                      int n_pad, int to_matrix) {
+  const int s = blockIdx.z, q = blockIdx.y, r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_pad) return;
+  cplx* f = A + (size_t)s * sys_stride + (size_t)r * lda + n_pad + q;
+  cplx* y = Y + ((size_t)s * nrhs + q) * n_pad + r;
+  if (to_matrix) *f = *y; else *y = *f;
+}
+
 int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_info, void* d_work,
                             size_t work_bytes, hipStream_t st, bool amax_ready) {
   if (nb <= 0 || n_pad <= 0) return BIEM_OK;
@@ -1704,15 +1802,26 @@ int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long 
   BIEM_LAUNCHCHK();
   if (gemm_rc != BIEM_OK) return gemm_rc;
   {
-    // back substitution; its pass over U also takes the multiplier / growth checks of the strip entries (nrhs == 0: the pass runs
-    // for the checks alone)
+    // back substitution (k_back_row, bottom block row first); its pass over U also takes the multiplier / growth checks of the
+    // strip entries (nrhs == 0: one pass for the checks alone); right-hand sides in groups of up to 8
     ProfScope ps(PK_BACK, st, 4.0 * (double)nb * n_pad * (double)n_pad * nrhs);
-    for (int jr = n_pad - BS; jr >= 0; jr -= BS) {
-      if (nrhs > 0) hipLaunchKernelGGL(k_back_diag, dim3(nb, nrhs), dim3(64), 0, st, A, lda, sys_stride, A + n_pad, lda, sys_stride, jr);
-      if (jr > 0)
-        hipLaunchKernelGGL(k_back_update, dim3((jr + BACK_ROWS - 1) / BACK_ROWS, nb), dim3(256), 0, st, A, lda, sys_stride, A + n_pad, lda,
-                           sys_stride, nrhs, jr, 0, jr, d_info, growth, 1.0 / (nopiv * nopiv));
-    }
+    const double inv_rel2 = 1.0 / (nopiv * nopiv);
+    cplx* Y = (cplx*)d_work;         // the panel region of the workspace is free in the row form: nb * nrhs * n_pad complex fit (checked below)
+    if ((size_t)nrhs > 4 * (size_t)NB) { set_error("biem_sym: at most %d right-hand sides per call", 4 * NB); return BIEM_ERR_ARG; }
+    if (nrhs > 0) hipLaunchKernelGGL(k_rhs_compact, dim3((n_pad + 255) / 256, nrhs, nb), dim3(256), 0, st, A, lda, sys_stride, Y, nrhs, n_pad, 0);
+    int q0 = 0;
+    do {
+      const int nq = nrhs - q0 > 8 ? 8 : nrhs - q0;
+      const int chk = q0 == 0 ? 1 : 0;
+      for (int ib = n_pad / NB - 1; ib >= 0; --ib) {
+        if (nq <= 1) hipLaunchKernelGGL(k_back_row<1>, dim3(nb), dim3(1024), 0, st, A, lda, sys_stride, Y, nrhs, n_pad, q0, nq, ib, chk, d_info, growth, inv_rel2);
+        else if (nq == 2) hipLaunchKernelGGL(k_back_row<2>, dim3(nb), dim3(1024), 0, st, A, lda, sys_stride, Y, nrhs, n_pad, q0, nq, ib, chk, d_info, growth, inv_rel2);
+        else if (nq <= 4) hipLaunchKernelGGL(k_back_row<4>, dim3(nb), dim3(1024), 0, st, A, lda, sys_stride, Y, nrhs, n_pad, q0, nq, ib, chk, d_info, growth, inv_rel2);
+        else hipLaunchKernelGGL(k_back_row<8>, dim3(nb), dim3(1024), 0, st, A, lda, sys_stride, Y, nrhs, n_pad, q0, nq, ib, chk, d_info, growth, inv_rel2);
+      }
+      q0 += nq;
+    } while (q0 < nrhs);
+    if (nrhs > 0) hipLaunchKernelGGL(k_rhs_compact, dim3((n_pad + 255) / 256, nrhs, nb), dim3(256), 0, st, A, lda, sys_stride, Y, nrhs, n_pad, 1);
     BIEM_LAUNCHCHK();
   }
   hipLaunchKernelGGL(k_growth_check, dim3((nb + 63) / 64), dim3(64), 0, st, nb, n_pad, growth, d_info, growth_max);
