@@ -658,9 +658,12 @@ def biem(
                 # torch's allocator).  The per-system kernels of the LU (panel strips, diagonal-block inverses, back
                 # substitution) are latency-bound on ONE CU per system, so they cost the same for 32 or 256 systems.
                 per = max(1, int(lib.biem_solve_workspace_bytes(plan.handle, 1, B, nrhs, 1)))
-                free, _total = torch.cuda.mem_get_info(dev)
-                avail = free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-                chunk = max(1, min(nb, 32768, int(0.85 * avail) // per))      # 32768: grid dimension of the per-system kernels
+                if nb * per <= (1 << 30):
+                    chunk = nb                     # small jobs: everything resident, no memory query (it costs more than the solve)
+                else:
+                    free, _total = torch.cuda.mem_get_info(dev)
+                    avail = free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+                    chunk = max(1, min(nb, 32768, int(0.85 * avail) // per))      # 32768: grid dimension of the per-system kernels
             wbytes = int(lib.biem_solve_workspace_bytes(plan.handle, nb, B, nrhs, chunk))
             work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
             density_t = torch.empty((nb, nrhs, B, H), dtype=torch.complex128, device=dev)
