@@ -411,7 +411,7 @@ def main() -> int:
             "share_of_step": ms[gi] / (dt * 1e3) if dt > 0 else None,
         },
         "fill": {"bound": "hbm", "achieved": fill_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fill_gbs / HBM_PEAK_GBS if fill_gbs else None,
-                 "bytes_counted": "16 N^2 per system (BIEM_SOLVER=lu) or what the L D L^T path reads: lower triangle + diagonal 64-blocks",
+                 "bytes_counted": "what the factorisation reads: upper triangle + diagonal 64 x 64 tiles of the symmetric form (default path), or 16 N^2 per system (BIEM_SOLVER=lu)",
                  "traffic": fill_traffic, "traffic_source": "profiles/r02_fill_traffic.json (rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE), scaled" if fill_traffic else None},
         "stage_ms_per_step": {n: m / args.steps for n, m in zip(CLASSES, ms)},
         "single_system_ms": single_ms,
