@@ -335,11 +335,21 @@ __global__ void k_fill_pad(int N, int n_pad, cplx* __restrict__ A, long long lda
   }
 }
 
+// does the one-unit-pair-per-lane form of the symmetric fill fit this plan's tables into LDS?
+static bool fill_sym_entry_fits(const biem_plan* p, size_t* shm_out) {
+  const size_t shm = (size_t)(p->H2lin + 2 * p->n_end) * sizeof(cplx) + (size_t)(p->qchunk_terms_max + 1) * 10 + (size_t)(2 * p->qchunk_pairs_max + 1) * 4 + 16;
+  if (shm_out) *shm_out = shm;
+  return p->pair_lists_ok && (int)p->qchunk.size() > 1 && shm <= 160 * 1024 && p->H2lin <= 8 * 1024;
+}
+
 size_t fill_workspace_bytes(const biem_plan* p, int nb, int B) {
-  // pair tables of the general / entry forms: [nb][B][B][H2]; of the systems-in-lanes form: [nb rounded up to 64][pairs][H2] + q factors
+  // pair tables of the general / entry forms: [nb][B][B][H2 or H2lin]; of the systems-in-lanes form (needed where the entry form
+  // does not fit, or when BIEM_FILL_FORM=sys forces it): [nb rounded up to 64][pairs][H2] + q factors
   const size_t a = (size_t)nb * B * B * (p->H2lin > p->H2 ? p->H2lin : p->H2), nbp = (size_t)(nb + 63) / 64 * 64;
   const size_t b = ((size_t)(B * (B - 1) / 2) * p->H2 + (size_t)B * p->n_end) * nbp;
-  return (a > b ? a : b) * sizeof(cplx);
+  const char* form = getenv("BIEM_FILL_FORM");
+  const bool need_sys = (form && form[0] == 's') || !fill_sym_entry_fits(p, nullptr);
+  return (need_sys && b > a ? b : a) * sizeof(cplx);
 }
 
 int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const double* d_centers, int geom_batched,
@@ -667,8 +677,8 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
   // system per lane, pair tables from L2 / Infinity Cache: bound by the ~35-70 GB/s a CU gets from there, 150 vs 92 ms per 256
   // systems at cfg 3) has no ceiling on the order and takes over where the entry form does not fit.  BIEM_FILL_FORM forces one.
   const char* form = getenv("BIEM_FILL_FORM");
-  const size_t shm_entry = (size_t)(p->H2lin + 2 * p->n_end) * sizeof(cplx) + (size_t)(p->qchunk_terms_max + 1) * 10 + (size_t)(2 * p->qchunk_pairs_max + 1) * 4 + 16;
-  const bool entry_fits = p->pair_lists_ok && (int)p->qchunk.size() > 1 && shm_entry <= 160 * 1024 && p->H2lin <= FILL_SYM_MAXT * FILL_SYM_THREADS;
+  size_t shm_entry = 0;
+  const bool entry_fits = fill_sym_entry_fits(p, &shm_entry);
   const bool sys_form = form ? (form[0] == 's') : !entry_fits;
   if (B > 1 && sys_form) {
     // systems in lanes.  Workspace: Tt[groups][npairs][H2][64] then Qt[groups][B][n_end][64] (fill_workspace_bytes covers it)

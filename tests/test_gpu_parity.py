@@ -905,7 +905,7 @@ def test_symmetric_fill_vs_transformed_general_fill(amd, lib, tree, n_end, B, ro
     cen_t, rad_t = _dev(cen[None]), _dev(rad[None])
     tab = torch.empty((nb, B, 3, n_end), dtype=torch.complex128, device="cuda")
     L.check(l.biem_ball_tables(plan.handle, nb, B, k_t.data_ptr(), eta_t.data_ptr(), rad_t.data_ptr(), 0, al.data_ptr(), be.data_ptr(), 0, tab.data_ptr(), None))
-    wb = max(l.biem_fill_workspace_bytes(plan.handle, nb, B), (B * (B - 1) // 2 * plan.H2 + B * n_end) * 64 * 16)   # the forced one-system-per-lane form pads the batch to 64
+    wb = l.biem_fill_workspace_bytes(plan.handle, nb, B)        # (with BIEM_FILL_FORM=sys it covers the batch padded to 64 systems)
     work = torch.empty(max(wb, 16), dtype=torch.uint8, device="cuda")
     M = torch.zeros((nb, npad, npad), dtype=torch.complex128, device="cuda")
     L.check(l.biem_fill(plan.handle, nb, B, k_t.data_ptr(), cen_t.data_ptr(), 0, tab.data_ptr(), L.FILL_EQUILIBRATED, M.data_ptr(), npad, npad * npad, npad, work.data_ptr(), wb, None))
