@@ -1806,8 +1806,20 @@ int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long 
     // strip entries (nrhs == 0: one pass for the checks alone); right-hand sides in groups of up to 8
     ProfScope ps(PK_BACK, st, 4.0 * (double)nb * n_pad * (double)n_pad * nrhs);
     const double inv_rel2 = 1.0 / (nopiv * nopiv);
-    cplx* Y = (cplx*)d_work;         // the panel region of the workspace is free in the row form: nb * nrhs * n_pad complex fit (checked below)
-    if ((size_t)nrhs > 4 * (size_t)NB) { set_error("biem_sym: at most %d right-hand sides per call", 4 * NB); return BIEM_ERR_ARG; }
+    cplx* Y = (cplx*)d_work;         // the panel region of the workspace is free in the row form: room for 4 * 64 right-hand sides per system
+    if (nrhs > 4 * NB) {
+      // more right-hand sides than the compact copy holds: the column-block form on the augmented columns (same checks)
+      for (int jr = n_pad - BS; jr >= 0; jr -= BS) {
+        hipLaunchKernelGGL(k_back_diag, dim3(nb, nrhs), dim3(64), 0, st, A, lda, sys_stride, A + n_pad, lda, sys_stride, jr);
+        if (jr > 0)
+          hipLaunchKernelGGL(k_back_update, dim3((jr + BACK_ROWS - 1) / BACK_ROWS, nb), dim3(256), 0, st, A, lda, sys_stride, A + n_pad, lda,
+                             sys_stride, nrhs, jr, 0, jr, d_info, growth, inv_rel2);
+      }
+      BIEM_LAUNCHCHK();
+      hipLaunchKernelGGL(k_growth_check, dim3((nb + 63) / 64), dim3(64), 0, st, nb, n_pad, growth, d_info, growth_max);
+      BIEM_LAUNCHCHK();
+      return BIEM_OK;
+    }
     if (nrhs > 0) hipLaunchKernelGGL(k_rhs_compact, dim3((n_pad + 255) / 256, nrhs, nb), dim3(256), 0, st, A, lda, sys_stride, Y, nrhs, n_pad, 0);
     int q0 = 0;
     do {

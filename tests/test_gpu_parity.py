@@ -945,7 +945,7 @@ def test_symmetric_fill_vs_transformed_general_fill(amd, lib, tree, n_end, B, ro
 
 # ---------------------------------------------------------------------------- the row-form symmetric factorisation (default path)
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,nb,nrhs", [(64, 2, 1), (150, 2, 2), (256, 1, 1), (300, 3, 1), (576, 2, 3), (1000, 2, 1), (1345, 1, 2), (700, 2, 12), (130, 1, 70)])
+@pytest.mark.parametrize("N,nb,nrhs", [(64, 2, 1), (150, 2, 2), (256, 1, 1), (300, 3, 1), (576, 2, 3), (1000, 2, 1), (1345, 1, 2), (700, 2, 12), (130, 1, 70), (200, 2, 300)])
 def test_sym_factor_solve_vs_numpy(lib, N, nb, nrhs):
     """biem_sym_factor_solve (A = U^T U in row form, what biem_solve_ldlt runs) on complex-symmetric matrices I + E against
     numpy.linalg.solve; only the UPPER triangle and the diagonal tiles may be read: the strict lower triangle outside the
