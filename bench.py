@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- BIEM systems solved per second on the BASELINE.json configurations (default: configs[2], the headline).
 
-One *step* = one pass of the whole hot path (boundary samples -> RHS projection -> fill -> complex-symmetric L D L^T, or the
+One *step* = one pass of the whole hot path (boundary samples -> RHS projection -> fill -> complex-symmetric U^T U factorisation, or the
 pivoted LU for systems it rejects / BIEM_SOLVER=lu -> density) over this rank's systems through the public `biem()` API;
 inputs are resident in HBM when the clock starts, the densities are resident in HBM when it stops.
 
@@ -400,7 +400,7 @@ def main() -> int:
         "max_rel_err_uscat": relerr,
         "roofline": {
             "bound": "mfma",
-            "kernel": "k_gemm3m_pipe<256> (zgemm3m K=256 trailing update of a four-panel group, v_mfma_f64_4x4x4_4b_f64; lower-triangle tiles in the L D L^T path)",
+            "kernel": "k_gemm3m_pipe<256> (zgemm3m K=256 trailing update of a four-panel group, v_mfma_f64_4x4x4_4b_f64; upper-triangle tiles in the symmetric path)",
             # `achieved` = flops the matrix pipe EXECUTES: the 3M form does a complex multiply-add in 3 real products = 6 real flops
             "achieved": issued, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": issued / FP64_MFMA_PEAK_TFLOPS if issued else None,

@@ -606,9 +606,10 @@ def biem(
     ``chunk`` (extension) bounds how many system matrices are resident at once (0 = choose).
 
     Solver: the reference passes every system to a general dense solve (``_biem.py:797``).  Here the system is first brought
-    to its complex-symmetric form (real harmonics, symmetric scaling) and factored as L D L^T without interchanges - half the
-    flops; a system in which a multiplier would exceed 2 is solved by the pivoted LU instead (``BIEM_SOLVER=lu`` in the
-    environment: pivoted LU for all).  Both give the reference's ``density`` to rounding.
+    to its complex-symmetric form (real harmonics, symmetric scaling) and factored as U^T U (Cholesky-type, no conjugation)
+    without interchanges - half the flops; a system in which a multiplier would exceed 2, or whose factor grew by more than
+    1e3, is solved by the pivoted LU instead (``BIEM_SOLVER=lu`` in the environment: pivoted LU for all).  Both give the
+    reference's ``density`` to rounding.
     """
     if translational_coefficients_method not in (None, "gumerov", "plane_wave", "triplet"):
         raise ValueError(f"Invalid translational_coefficients_method: {translational_coefficients_method}")
@@ -669,7 +670,7 @@ def biem(
             density_t = torch.empty((nb, nrhs, B, H), dtype=torch.complex128, device=dev)
             info = torch.zeros(nb, dtype=torch.int32, device=dev)
             # The equilibrated system is complex symmetric in a real-harmonic basis (include/biem_mi355.h, biem_solve_ldlt):
-            # L D L^T without interchanges, half the flops of the LU.  Systems whose diagonal pivots were rejected
+            # U^T U factorisation without interchanges, half the flops of the LU.  Systems whose diagonal pivots were rejected
             # (info < 0: close to a resonance of a sphere, or strongly coupled spheres) are solved again with the pivoted LU,
             # which is what the reference's linalg.solve does for every system (_biem.py:797).  BIEM_SOLVER=lu: LU only.
             solver = os.environ.get("BIEM_SOLVER", "ldlt")

@@ -47,7 +47,7 @@ extern "C" {
 #define BIEM_FILL_REFERENCE 0    /* A = blc_{n'} * { diag(alpha h + beta k h') | (S|R)^T (alpha j + beta k j') }  (_biem.py:745-792) */
 #define BIEM_FILL_EQUILIBRATED 1 /* M = I + (S|R)^T (alpha j+beta k j')_row / (alpha h+beta k h')_col : what the LU factors */
 #define BIEM_FILL_SYMMETRIC 2    /* A~ = R W^H M W R^-1, complex symmetric (W: unitary map to real harmonics, R = diag(1/sqrt(gj gh))):
-                                    what the L D L^T path factors.  Rows / columns of a ball in the internal slot order of
+                                    what the symmetric path factors.  Rows / columns of a ball in the internal slot order of
                                     biem_plan_symmetric_order; ONLY the upper triangle and the diagonal 64 x 64 tiles are written
                                     (n_pad must be a multiple of 64, lda >= n_pad); everything else is left untouched */
 
