@@ -289,14 +289,17 @@ static int solve_impl(const biem_plan* plan, int nb, int B, int nrhs, const doub
     const double* cen = d_centers + (geom_batched ? (size_t)s0 * B * d : 0);
     const double* tb = tab + (size_t)s0 * B * 3 * plan->n_end * 2;
     // right-hand side into column n_pad of the augmented matrix (padded rows: zero via fill_pad? -> set explicitly below)
+    // small systems are solved in one LDS-resident launch that never reads the padding rows / columns: they are not written then
+    const bool small = symmetric && sym_small_path(L.N, nrhs);
     if (symmetric)
-      rc = launch_fill_sym(plan, c, B, ks, cen, geom_batched, tb, A, L.lda, L.sys_stride, L.n_pad, T, fill_workspace_bytes(plan, c, B), st);
+      rc = launch_fill_sym(plan, c, B, ks, cen, geom_batched, tb, A, L.lda, L.sys_stride, L.n_pad, T, fill_workspace_bytes(plan, c, B), st, small);
     else
       rc = launch_fill(plan, c, B, ks, cen, geom_batched, tb, BIEM_FILL_EQUILIBRATED, A, L.lda, L.sys_stride, L.n_pad, T,
                        fill_workspace_bytes(plan, c, B), st);
     if (rc) return rc;
-    BIEM_HIPCHK(hipMemset2DAsync(A + (size_t)L.n_pad * 2, (size_t)L.lda * 16, 0, (size_t)(L.lda - L.n_pad) * 16,
-                                 (size_t)L.n_pad * c, st));
+    if (!small)
+      BIEM_HIPCHK(hipMemset2DAsync(A + (size_t)L.n_pad * 2, (size_t)L.lda * 16, 0, (size_t)(L.lda - L.n_pad) * 16,
+                                   (size_t)L.n_pad * c, st));
     rc = launch_rhs_project(plan, c, B, nrhs, d_g + (size_t)s0 * nrhs * B * Q * 2, A + (size_t)L.n_pad * 2, L.sys_stride, L.lda, 1, st, symmetric);
     if (rc) return rc;
     bool amax_ready = false;
@@ -310,7 +313,7 @@ static int solve_impl(const biem_plan* plan, int nb, int B, int nrhs, const doub
       amax_ready = true;
     }
     if (symmetric)
-      rc = launch_sym_factor_solve(c, L.n_pad, nrhs, A, L.lda, L.sys_stride, d_info + s0, Pw, lu_workspace_bytes(c, L.n_pad, nrhs), st, amax_ready);
+      rc = launch_sym_factor_solve(c, L.n_pad, nrhs, A, L.lda, L.sys_stride, d_info + s0, Pw, lu_workspace_bytes(c, L.n_pad, nrhs), st, amax_ready, L.N);
     else
       rc = launch_lu_factor_solve(c, L.n_pad, nrhs, A, L.lda, L.sys_stride, ipiv, d_info + s0, Pw, lu_workspace_bytes(c, L.n_pad, nrhs), st,
                                   /*keep_multipliers=*/false, false, false);   // the fused path only needs the solution

@@ -84,7 +84,7 @@ int launch_density(const biem_plan* p, int nb, int B, int nrhs, const double* d_
 // the complex-symmetric form A~ = R W^H M W R^-1 in the plan's internal slot order, written only where the L D L^T factorisation
 // reads it (lower triangle + diagonal 64 x 64 tiles); fill_sym_bytes = those bytes per system
 int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const double* d_centers, int geom_batched, const double* d_tab,
-                    double* d_A, long long lda, long long sys_stride, int n_pad, void* d_work, size_t work_bytes, hipStream_t st);
+                    double* d_A, long long lda, long long sys_stride, int n_pad, void* d_work, size_t work_bytes, hipStream_t st, bool no_padding = false);
 double fill_sym_bytes(int n_pad);
 int launch_uscat(const biem_plan* p, int nb, int B, int P, const double* d_k, const double* d_eta, const double* d_centers,
                  const double* d_radii, int geom_batched, const double* d_density, const double* d_points, int flags,
@@ -95,8 +95,10 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
                            int* d_info, void* d_work, size_t work_bytes, hipStream_t st, bool keep_multipliers = true,
                            bool symmetric = false, bool amax_ready = false);
 // complex-symmetric A = U^T U in row form on the upper triangle (kernels_lu.hip), fused with the solve of the augmented columns
+bool sym_small_path(int n_active, int nrhs);      // whether launch_sym_factor_solve takes its one-launch LDS-resident path
+// (n_active: rows n_active .. n_pad-1 are identity padding; systems of at most 96 active rows run in one LDS-resident launch)
 int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_info, void* d_work,
-                            size_t work_bytes, hipStream_t st, bool amax_ready = false);
+                            size_t work_bytes, hipStream_t st, bool amax_ready = false, int n_active = 0);
 // where the symmetric factorisation keeps max |A|, max |U| per system inside its workspace (unsigned 64-bit patterns of doubles)
 unsigned long long* lu_growth_slots(void* d_work, int nb, int n_pad);
 // preset the slots for a caller that knows (a lower bound of) max |A|: growth[s] = (amax, 0); then pass amax_ready = true

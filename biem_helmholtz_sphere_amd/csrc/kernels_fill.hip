@@ -646,7 +646,7 @@ __global__ void __launch_bounds__(FILL_SYS_THREADS) k_fill_sys(int H, int U, int
 
 // what k_fill_sym leaves: the identity diagonal blocks and the padding, again only where the factorisation reads
 // (columns c >= 64 (r / 64) of row r); one workgroup per row
-__global__ void __launch_bounds__(64) k_fill_sym_diag(int H, int N, int n_pad, cplx* __restrict__ A, long long lda, long long sys_stride) {
+__global__ void __launch_bounds__(64) k_fill_sym_diag(int H, int N, int n_pad, cplx* __restrict__ A, long long lda, long long sys_stride, int no_pad) {
   const int r = blockIdx.x, s = blockIdx.y;
   cplx* row = A + (size_t)s * sys_stride + (size_t)r * lda;
   const int c0 = (r / 64) * 64;
@@ -654,7 +654,7 @@ __global__ void __launch_bounds__(64) k_fill_sym_diag(int H, int N, int n_pad, c
   if (r >= N) { for (int c = c0 + threadIdx.x; c < n_pad; c += 64) put(c); return; }
   const int br = r / H, bend = (br + 1) * H;              // this row's own ball: columns [br H, bend)
   for (int c = (c0 > br * H ? c0 : br * H) + threadIdx.x; c < bend; c += 64) put(c);
-  for (int c = N + threadIdx.x; c < n_pad; c += 64) put(c);
+  if (!no_pad) for (int c = N + threadIdx.x; c < n_pad; c += 64) put(c);
 }
 
 // bytes of one system the symmetric path writes and the factorisation reads: sum over rows of 16 * 64 (r / 64 + 1)
@@ -664,7 +664,7 @@ double fill_sym_bytes(int n_pad) {
 }
 
 int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const double* d_centers, int geom_batched, const double* d_tab,
-                    double* d_A, long long lda, long long sys_stride, int n_pad, void* d_work, size_t work_bytes, hipStream_t st) {
+                    double* d_A, long long lda, long long sys_stride, int n_pad, void* d_work, size_t work_bytes, hipStream_t st, bool no_padding) {
   const int H = p->H, N = B * H, U = (int)(p->units.size() / 2);
   if (nb <= 0 || B <= 0) return BIEM_OK;
   if (lda < n_pad || n_pad < N || n_pad % 64) { set_error("biem_fill (symmetric): lda / n_pad too small or n_pad not a multiple of 64"); return BIEM_ERR_ARG; }
@@ -739,7 +739,8 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
 #undef BIEM_LAUNCH_FILL_SYM
     BIEM_LAUNCHCHK();
   }
-  hipLaunchKernelGGL(k_fill_sym_diag, dim3(n_pad, nb), dim3(64), 0, st, H, N, n_pad, (cplx*)d_A, lda, sys_stride);
+  // (no_padding: the caller's solver never reads the identity padding - the LDS-resident path of small systems)
+  hipLaunchKernelGGL(k_fill_sym_diag, dim3(no_padding ? N : n_pad, nb), dim3(64), 0, st, H, N, n_pad, (cplx*)d_A, lda, sys_stride, no_padding ? 1 : 0);
   BIEM_LAUNCHCHK();
   return BIEM_OK;
 }

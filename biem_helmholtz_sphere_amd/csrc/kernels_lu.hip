@@ -48,13 +48,14 @@ size_t lu_workspace_bytes(int nb, int n_pad, int nrhs) {
 constexpr double GROWTH_MAX = 1.0e3;
 __device__ inline double cabs1(cplx v) { return fabs(v.x) + fabs(v.y); }
 __device__ inline double nan_max(double a, double b) { return !(b <= a) ? b : a; }       // NaN in b wins; NaN in a stays
-__device__ inline void block_max_publish(double m, unsigned long long* dst) {              // 256-thread blocks
-  __shared__ double sm_max[4];
+__device__ inline void block_max_publish(double m, unsigned long long* dst) {              // 1-D blocks of whole waves
+  __shared__ double sm_max[16];
   for (int o = 32; o > 0; o >>= 1) m = nan_max(m, __shfl_down(m, o, 64));
   if ((threadIdx.x & 63) == 0) sm_max[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    m = nan_max(nan_max(sm_max[0], sm_max[1]), nan_max(sm_max[2], sm_max[3]));
+    m = sm_max[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = nan_max(m, sm_max[i]);
     // most workgroups cannot raise the maximum: a plain read filters them out (the slot only grows, so a stale value is safe)
     if (!(m <= __longlong_as_double((long long)*(volatile unsigned long long*)dst))) atomicMax(dst, (unsigned long long)__double_as_longlong(m));
   }
@@ -1741,9 +1742,132 @@ __global__ void __launch_bounds__(256) k_rhs_compact(cplx* __restrict__ A, long 
   if (to_matrix) *f = *y; else *y = *f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small systems (cfg 1: N = 72): the whole augmented system in LDS, one workgroup per system, ONE launch for factorisation,
+// forward elimination, checks and back substitution - the blocked path above spends its time in per-panel launches there
+// (4096 systems of N = 72: 5.2 of 6.8 ms in diagonal-block kernels that run one 64 x 64 block per workgroup).
+// Same factorisation A = U^T U on the upper triangle (rows n .. of an identity-padded system are skipped), same acceptance tests
+// and info codes; U is written back to the upper triangle.  n <= 96 rows and nrhs <= 8 (n (n + nrhs + 1) complex of LDS).
+// ---------------------------------------------------------------------------------------------
+constexpr int SMALL_N_MAX = 96;
+constexpr int SMALL_RHS_MAX = 8;
+constexpr int SMALL_THREADS = 512;
+// LDS of k_small_utu: packed upper triangle with the right-hand sides appended to each row, then 1/a_cc and 1/sqrt(a_cc) per row
+// and two rows of multipliers
+static inline size_t small_utu_lds(int n, int nrhs) { return ((size_t)n * (n + 1) / 2 + (size_t)n * nrhs + 4 * (size_t)n) * sizeof(cplx); }
+// The matrix lives in registers during the elimination: wave w owns rows w, w + 8, ... (KR of them), lane l columns l and l + 64
+// (TWO); a finished row (row c + 1 after step c) is published once to the packed LDS store, which the other waves read it from
+// and which the back substitution and the write-back then use.  One barrier per step, no read-modify-write through LDS.
+template <int KR, bool TWO>
+__global__ void __launch_bounds__(SMALL_THREADS, 4) k_small_utu(cplx* __restrict__ A, long long lda, long long sys_stride, int n, int n_pad, int nrhs,
+                                                              int* __restrict__ info, unsigned long long* __restrict__ growth, double rel, int amax_ready) {
+  // row r of the packed store: columns r .. n-1 of the matrix, then the nrhs right-hand sides; element (r, c) at off(r) + c, nc = n + nrhs
+  extern __shared__ cplx sa[];
+  __shared__ int bad_row;
+  constexpr int NW = SMALL_THREADS / 64;
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nc = n + nrhs;
+  auto off = [&](int r) { return r * nc - (r * (r - 1)) / 2 - r; };
+  cplx* ipiv = sa + (size_t)n * (n + 1) / 2 + (size_t)n * nrhs;            // 1 / a_cc
+  cplx* isq = ipiv + n;                                                     // 1 / sqrt(a_cc)
+  cplx* lrow = isq + n;                                                     // [2][n]: the multipliers a_cj / a_cc of the current row
+  cplx* As = A + (size_t)s * sys_stride;
+  if (tid == 0) bad_row = -1;
+  const int j0 = lane, j1 = lane + 64;
+  const long long g0 = j0 < n ? j0 : n_pad + (j0 - n), g1 = j1 < n ? j1 : n_pad + (j1 - n);     // global columns of the two slots
+  cplx a0[KR], a1[KR];
+  double am = 0.0;                               // (squares; the root is taken once)
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+    const int i = w + NW * k;
+    a0[k] = a1[k] = make_double2(0.0, 0.0);
+    if (i < n) {
+      const cplx* src = As + (size_t)i * lda;
+      if (j0 >= i && j0 < nc) { a0[k] = src[g0]; if (j0 < n) am = nan_max(am, a0[k].x * a0[k].x + a0[k].y * a0[k].y); }
+      if (TWO && j1 >= i && j1 < nc) { a1[k] = src[g1]; if (j1 < n) am = nan_max(am, a1[k].x * a1[k].x + a1[k].y * a1[k].y); }
+    }
+  }
+  // A finished row i: its wave publishes it (packed store), 1 / a_ii (ipiv) and the multipliers a_ij / a_ii (lrow[i & 1]);
+  // the reciprocal is computed here ONCE per row (plain 1 / |d|^2 form: the systems are equilibrated, |a_ii| = O(1); an
+  // overflow would surface as inf / NaN in the growth test)
+  auto publish = [&](int i, const cplx& r0, const cplx& r1) {
+    cplx d;
+    if (!TWO || i < 64) { d.x = __shfl(r0.x, i & 63, 64); d.y = __shfl(r0.y, i & 63, 64); }
+    else { d.x = __shfl(r1.x, i & 63, 64); d.y = __shfl(r1.y, i & 63, 64); }
+    const double rr = 1.0 / (d.x * d.x + d.y * d.y);
+    const cplx ip = make_double2(d.x * rr, -d.y * rr);
+    cplx* ri = sa + off(i);
+    cplx* lr = lrow + (i & 1) * n;
+    if (j0 >= i && j0 < nc) { ri[j0] = r0; if (j0 < n) lr[j0] = cmul(r0, ip); }
+    if (TWO && j1 >= i && j1 < nc) { ri[j1] = r1; if (j1 < n) lr[j1] = cmul(r1, ip); }
+    if (lane == 0) ipiv[i] = ip;
+  };
+  if (w == 0) publish(0, a0[0], a1[0]);          // row 0 is final from the start
+  if (!amax_ready) block_max_publish(sqrt(am), growth + 2 * (size_t)s);
+  // Elimination in the D L^T form (row c stays unscaled: a_ij -= (a_ci / a_cc) a_cj); U = D^{-1/2} (D L^T) at the write-back.
+  double um = 0.0;
+  for (int c = 0; c < n; ++c) {
+    __syncthreads();                            // row c has been published
+    const cplx* rc = sa + off(c);
+    const cplx* lr = lrow + (c & 1) * n;
+    const cplx u0 = rc[(j0 >= c && j0 < nc) ? j0 : c];
+    const cplx u1 = TWO ? rc[(j1 >= c && j1 < nc) ? j1 : c] : make_double2(0.0, 0.0);
+    if (w == ((c + 1 + NW / 2) & (NW - 1))) {
+      // acceptance tests on row c, once (by a wave that does not publish the next row): multipliers |a_cj| <= |piv| / rel;
+      // growth: |a_cj| is the D L^T entry
+      const cplx piv = rc[c];
+      const double pa = fabs(piv.x) + fabs(piv.y);
+      const bool in0 = j0 >= c && j0 < n, in1 = TWO && j1 >= c && j1 < n;
+      const double v0 = in0 ? fabs(u0.x) + fabs(u0.y) : 0.0, v1 = in1 ? fabs(u1.x) + fabs(u1.y) : 0.0;
+      if ((in0 && j0 > c && !(pa >= rel * v0)) || (in1 && j1 > c && !(pa >= rel * v1)) || !(pa > 0.0)) atomicMax(&bad_row, n - 1 - c);
+      if (in0) um = nan_max(um, u0.x * u0.x + u0.y * u0.y);
+      if (in1) um = nan_max(um, u1.x * u1.x + u1.y * u1.y);
+    }
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const int i = w + NW * k;
+      if (i > c && i < n) {
+        const cplx f = lr[i];
+        if (k < 64 / NW) a0[k] = cfnma(f, u0, a0[k]);         // (rows from 64 on have nothing in columns 0 .. 63)
+        if (TWO) a1[k] = cfnma(f, u1, a1[k]);
+        if (i == c + 1) publish(i, a0[k], a1[k]);             // this row is final now
+      }
+    }
+  }
+  __syncthreads();
+  for (int r = tid; r < n; r += SMALL_THREADS) isq[r] = crecip(zsqrt(sa[off(r) + r]));
+  um = sqrt(um);
+  block_max_publish(um, growth + 2 * (size_t)s + 1);
+  // back substitution (D L^T) x = y': x_c = (y'_c - sum_{j > c} a_cj x_j) / a_cc, column oriented, one barrier per step:
+  // y'_c is final when step c starts; thread i < c takes a_ic x_c off y'_i; x_c = y'_c / a_cc is formed again at the write-back
+  for (int c = n - 1; c > 0; --c) {
+    __syncthreads();
+    const cplx* rc = sa + off(c);
+    const cplx ip = ipiv[c];
+    for (int i = tid; i < c; i += SMALL_THREADS) {
+      cplx* ri = sa + off(i);
+      const cplx aic = ri[c];
+      for (int q = 0; q < nrhs; ++q) ri[n + q] = cfnma(aic, cmul(rc[n + q], ip), ri[n + q]);
+    }
+  }
+  __syncthreads();
+  for (int r = w; r < n; r += SMALL_THREADS / 64) {
+    cplx* dstg = As + (size_t)r * lda;
+    const cplx* src = sa + off(r);
+    const cplx sc = isq[r], ip = ipiv[r];
+    for (int c = r + lane; c < nc; c += 64) {
+      if (c < n) dstg[c] = cmul(src[c], sc);                  // U = D^{-1/2} (D L^T)
+      else dstg[n_pad + (c - n)] = cmul(src[c], ip);         // the solution
+    }
+  }
+  if (tid == 0 && bad_row >= 0 && info[s] == 0) info[s] = -(((n - 1 - bad_row) / NB) * NB + 1);
+}
+
+bool sym_small_path(int n_active, int nrhs) { return n_active > 0 && n_active <= SMALL_N_MAX && nrhs <= SMALL_RHS_MAX && !getenv("BIEM_NO_SMALL_PATH"); }
+
 int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_info, void* d_work,
-                            size_t work_bytes, hipStream_t st, bool amax_ready) {
+                            size_t work_bytes, hipStream_t st, bool amax_ready, int n_active) {
   if (nb <= 0 || n_pad <= 0) return BIEM_OK;
+  if (n_active <= 0 || n_active > n_pad) n_active = n_pad;        // rows n_active .. n_pad-1: identity padding (the caller's promise)
   if (n_pad % NB) { set_error("biem_sym: n_pad=%d is not a multiple of %d (use biem_lu_npad)", n_pad, NB); return BIEM_ERR_ARG; }
   if (nrhs < 0 || lda < n_pad + nrhs) { set_error("biem_sym: lda < n_pad + nrhs"); return BIEM_ERR_ARG; }
   if (nb > 65535 || nrhs > 65535) { set_error("biem_sym: at most 65535 systems / right-hand sides per call (got %d / %d)", nb, nrhs); return BIEM_ERR_ARG; }
@@ -1757,6 +1881,28 @@ int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long 
   double nopiv = NOPIV_REL, growth_max = GROWTH_MAX;
   { const char* e = getenv("BIEM_LDLT_PIVOT_REL"); if (e && atof(e) > 0.0) nopiv = atof(e);
     const char* g = getenv("BIEM_LDLT_GROWTH_MAX"); if (g && atof(g) > 0.0) growth_max = atof(g); }
+  if (sym_small_path(n_active, nrhs)) {
+    // the whole system fits LDS: one launch does everything
+    if (!amax_ready) hipLaunchKernelGGL(k_zero_int, dim3((4 * nb + 63) / 64), dim3(64), 0, st, (int*)growth, 4 * nb);   // max|A| is measured by the kernel
+    ProfScope ps(PK_PANEL, st, 0.0);
+    const size_t shm = small_utu_lds(n_active, nrhs);
+    const bool two = n_active + nrhs > 64;
+    const int kr = (n_active + SMALL_THREADS / 64 - 1) / (SMALL_THREADS / 64);
+#define BIEM_SMALL(KR, TWO)                                                                                                         \
+  {                                                                                                                                  \
+    BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_small_utu<KR, TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));        \
+    hipLaunchKernelGGL((k_small_utu<KR, TWO>), dim3(nb), dim3(SMALL_THREADS), shm, st, A, lda, sys_stride, n_active, n_pad, nrhs, d_info, \
+                       growth, nopiv, amax_ready ? 1 : 0);                                                                              \
+  }
+    if (!two) { if (kr <= 4) BIEM_SMALL(4, false) else BIEM_SMALL(8, false) }
+    else if (kr <= 8) BIEM_SMALL(8, true)
+    else if (kr <= 9) BIEM_SMALL(9, true)
+    else BIEM_SMALL(12, true)
+#undef BIEM_SMALL
+    hipLaunchKernelGGL(k_growth_check, dim3((nb + 63) / 64), dim3(64), 0, st, nb, n_pad, growth, d_info, growth_max);
+    BIEM_LAUNCHCHK();
+    return BIEM_OK;
+  }
   {
     const int T = n_pad / NB, fb = T / 8, n_map = 32 * fb * fb + 4 * fb;
     if (n_map > 0) hipLaunchKernelGGL(k_tri_map, dim3((n_map + 255) / 256), dim3(256), 0, st, tri_map, n_map);

@@ -497,6 +497,36 @@ def test_many_small_systems_are_chunked(amd):
         assert abs(u[i] - O.uscat(res, np.zeros((1, 3)))[0]) < 1e-11 * abs(u[i]), i
 
 
+@pytest.mark.parametrize("bt,d,n_end,B", [("ba", 3, 6, 2), ("ba", 3, 4, 5), ("a", 2, 9, 5), ("ba", 3, 3, 9)])
+def test_small_systems_one_launch_path(amd, bt, d, n_end, B, monkeypatch):
+    """Systems of at most 96 unknowns are factorised and solved in ONE launch with the whole system in LDS (k_small_utu), larger
+    ones by the blocked row form: both on the same inputs (BIEM_NO_SMALL_PATH=1 forces the blocked one) and against the oracle.
+    N = 72 (cfg 1), 80, 85 and 81 - one to three 64-row panels of the blocked path, every register layout of the small one."""
+    c = amd.create_from_branching_types(bt)
+    rng = np.random.default_rng(B * 7 + n_end)
+    cen = np.zeros((B, d)); cen[:, 0] = 2.6 * np.arange(B); cen[:, 1:] = 0.3 * rng.normal(size=(B, d - 1))
+    rad = 0.7 + 0.3 * rng.random(B)
+    ks = np.array([0.9, 1.7, 2.4])
+    dirs = np.zeros((d, len(ks))); dirs[0] = 1.0
+    x = 10.0 + rng.normal(size=(4, d))
+
+    def run():
+        uin, ugr = amd.plane_wave(k=_dev(ks), direction=_dev(dirs))
+        calc = amd.biem(c, centers=_dev(cen)[None], radii=_dev(rad)[None], k=_dev(ks), n_end=n_end, alpha=1.0, beta=0.5j, uin=uin, uin_grad=ugr)
+        return calc.uscat(_dev(x.T)).cpu().numpy()
+
+    u_small = run()
+    monkeypatch.setenv("BIEM_NO_SMALL_PATH", "1")
+    u_blocked = run()
+    assert np.max(np.abs(u_small - u_blocked)) < 1e-12 * np.max(np.abs(u_blocked))
+    for i, k in enumerate(ks):
+        e0 = np.zeros(d); e0[0] = 1.0
+        uo, go = O.plane_wave(k, e0)
+        res = O.solve_biem(bt, centers=cen, radii=rad, k=k, n_end=n_end, alpha=1.0, beta=0.5j, uin=uo, uin_grad=go)
+        ref = O.uscat(res, x)
+        assert np.max(np.abs(u_small[:, i] - ref)) < 1e-10 * np.max(np.abs(ref)), i
+
+
 @pytest.mark.parametrize("force_lu_fallback", [False, True])
 def test_batched_geometry_and_points_per_system(amd, force_lu_fallback, monkeypatch):
     """(force_lu_fallback: every system is rejected by the symmetric path and re-solved by the pivoted LU from gathered
@@ -545,7 +575,7 @@ def test_lu_solve_without_stored_factors(lib, N, nb, nrhs, monkeypatch):
 
 # ---------------------------------------------------------------------------- complex-symmetric L D L^T path
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,nb,nrhs", [(64, 2, 1), (150, 2, 2), (256, 1, 1), (300, 3, 1), (576, 2, 3), (1000, 2, 1), (1345, 1, 2), (700, 2, 12)])
+@pytest.mark.parametrize("N,nb,nrhs", [(64, 2, 1), (17, 3, 2), (40, 2, 8), (64, 300, 8), (150, 2, 2), (256, 1, 1), (300, 3, 1), (576, 2, 3), (1000, 2, 1), (1345, 1, 2), (700, 2, 12)])
 @pytest.mark.parametrize("discard", [False, True])
 def test_ldlt_factor_solve_vs_numpy(lib, N, nb, nrhs, discard, monkeypatch):
     """biem_ldlt_factor_solve on complex-symmetric (not Hermitian) matrices I + E; only the lower triangle may be read: the
@@ -945,7 +975,7 @@ def test_symmetric_fill_vs_transformed_general_fill(amd, lib, tree, n_end, B, ro
 
 # ---------------------------------------------------------------------------- the row-form symmetric factorisation (default path)
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,nb,nrhs", [(64, 2, 1), (150, 2, 2), (256, 1, 1), (300, 3, 1), (576, 2, 3), (1000, 2, 1), (1345, 1, 2), (700, 2, 12), (130, 1, 70), (200, 2, 300)])
+@pytest.mark.parametrize("N,nb,nrhs", [(64, 2, 1), (17, 3, 2), (40, 2, 8), (64, 300, 8), (150, 2, 2), (256, 1, 1), (300, 3, 1), (576, 2, 3), (1000, 2, 1), (1345, 1, 2), (700, 2, 12), (130, 1, 70), (200, 2, 300)])
 def test_sym_factor_solve_vs_numpy(lib, N, nb, nrhs):
     """biem_sym_factor_solve (A = U^T U in row form, what biem_solve_ldlt runs) on complex-symmetric matrices I + E against
     numpy.linalg.solve; only the UPPER triangle and the diagonal tiles may be read: the strict lower triangle outside the
@@ -1025,5 +1055,32 @@ def test_sym_factor_rejections_and_growth(lib, monkeypatch):
     assert run(B) == [0, 0]
     monkeypatch.delenv("BIEM_LDLT_GROWTH_MAX")
     B[1, 20, 150] = np.nan
+    bad = run(B)
+    assert bad[0] == 0 and bad[1] < 0
+    # the same acceptance tests in the one-launch path of small systems (at most 96 active rows, the whole system in LDS)
+    N = 64
+    A = np.zeros((4, N, N + 8), dtype=np.complex128)
+    A[:, :, :N] = np.eye(N)
+    A[:, :, N] = 1.0
+    A[1, 10, 10] = 0.01
+    A[1, 10, 50] = A[1, 50, 10] = 1.0
+    A[2, 63, 63] = 0.0
+    A[3, 5, 40] = A[3, 40, 5] = 0.4                             # multiplier 0.4: accepted
+    assert run(A) == [0, -1, -1, 0]
+    As = (np.eye(N) * (1.0 + 0.2j) + (E + E.T)[:N, :N])
+    M = As.copy()
+    for c in range(N):
+        M[c + 1:, c] /= M[c, c]
+        M[c + 1:, c + 1:] -= np.outer(M[c + 1:, c], M[c, c + 1:])
+    ratio = np.abs(np.triu(M)).max() / np.abs(As).max()
+    B = np.zeros((2, N, N + 8), dtype=np.complex128)
+    B[:, :, :N] = As
+    B[:, :, N] = 1.0
+    monkeypatch.setenv("BIEM_LDLT_GROWTH_MAX", repr(float(0.99 * ratio)))
+    assert run(B) == [-(N + 1)] * 2
+    monkeypatch.setenv("BIEM_LDLT_GROWTH_MAX", repr(float(1.01 * ratio)))
+    assert run(B) == [0, 0]
+    monkeypatch.delenv("BIEM_LDLT_GROWTH_MAX")
+    B[1, 20, 50] = np.nan
     bad = run(B)
     assert bad[0] == 0 and bad[1] < 0
