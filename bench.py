@@ -382,6 +382,14 @@ def main() -> int:
     fill_traffic = fj["bytes_per_system"] * nloc if fj and cfg == 3 else None
 
     issued = 0.75 * alg_tflops if alg_tflops else None     # 3M: 3 real products per complex multiply-add = 6 of the 8 flops
+    # what a pure stream of the same MFMA instruction sustains on THIS box (0.3 s, after the timed region): context for `frac`,
+    # which stays priced against the nominal 78.6 TFLOP/s
+    sustained = None
+    if rank == 0:
+        import ctypes as C
+        tf = C.c_double()
+        L.check(lib.biem_bench_mfma_f64_ex(2000000, 1, C.byref(tf), None))
+        sustained = tf.value
     out = {
         "metric": "BIEM systems solved/sec + max |u_scat| rel-err vs NumPy ref",
         "value": value,
@@ -406,6 +414,7 @@ def main() -> int:
             "frac": issued / FP64_MFMA_PEAK_TFLOPS if issued else None,
             # the same launches priced at the textbook 8 real flops per complex multiply-add (what a 4M zgemm would execute)
             "algorithmic_tflops_8flop": alg_tflops,
+            "pure_mfma_stream_tflops": sustained, "frac_of_pure_mfma_stream": issued / sustained if issued and sustained else None,
             "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_ms": ms[gi] / launches[gi] if launches[gi] else None, "launches": launches[gi],
             "share_of_step": ms[gi] / (dt * 1e3) if dt > 0 else None,

@@ -58,6 +58,7 @@ SIGNATURES = {
     "biem_profile_begin": (_i, []),
     "biem_profile_end": (_i, [_vp, _vp, _vp]),
     "biem_bench_mfma_f64": (_i, [_i, C.POINTER(C.c_double), _vp]),
+    "biem_bench_mfma_f64_ex": (_i, [_i, _i, C.POINTER(C.c_double), _vp]),
 }
 
 _lock = threading.Lock()

@@ -374,5 +374,10 @@ int biem_bench_mfma_f64(int iters, double* tflops, void* stream) {
   NEED(tflops, "tflops");
   return bench_mfma_f64(iters, tflops, (hipStream_t)stream);
 }
+int biem_bench_mfma_f64_ex(int iters, int variant, double* tflops, void* stream) {
+  NEED(tflops, "tflops");
+  if (iters <= 0 || (variant != 0 && variant != 1)) { set_error("biem_bench_mfma_f64_ex: iters > 0, variant 0 or 1"); return BIEM_ERR_ARG; }
+  return bench_mfma_f64(iters, tflops, (hipStream_t)stream, variant);
+}
 
 }  // extern "C"

@@ -108,6 +108,6 @@ int launch_sym_rhs(const biem_plan* p, int nb, int B, int nrhs, int n_pad, const
                    long long sys_stride, bool inverse_on_solution, hipStream_t st);
 int launch_lu_solve(int nb, int n_pad, int nrhs, const double* d_LU, long long lda, long long sys_stride, const int* d_ipiv, double* d_B,
                     long long ldb, long long b_stride, hipStream_t st);
-int bench_mfma_f64(int iters, double* tflops, hipStream_t st);
+int bench_mfma_f64(int iters, double* tflops, hipStream_t st, int variant = 0);
 
 }  // namespace biem

@@ -2018,34 +2018,50 @@ int launch_lu_solve(int nb, int n_pad, int nrhs, const double* d_LU, long long l
 // ---------------------------------------------------------------------------------------------
 // microbenchmark: issue rate of v_mfma_f64_16x16x4_f64 (confirms the FP64 matrix peak the roofline is priced against)
 // ---------------------------------------------------------------------------------------------
+// V = 0: v_mfma_f64_16x16x4_f64 (2048 flops, 32 cycles);  V = 1: v_mfma_f64_4x4x4_4b_f64, the instruction of k_gemm3m_pipe (512 flops,
+// 16 cycles).  Both price at 32 flops per cycle and SIMD.
+template <int V>
 __global__ void __launch_bounds__(256) k_bench_mfma(int iters, double* sink) {
   v4d acc[8];
+  double acc1[16];
   for (int i = 0; i < 8; ++i) acc[i] = (v4d){0, 0, 0, 0};
+  for (int i = 0; i < 16; ++i) acc1[i] = 0.0;
   double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
   for (int it = 0; it < iters; ++it) {
+    if (V == 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc1[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc1[i], 0, 0, 0);
+    }
   }
   double sacc = 0.0;
   for (int i = 0; i < 8; ++i) sacc += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  for (int i = 0; i < 16; ++i) sacc += acc1[i];
   if (sacc == 123.456) sink[0] = sacc;
 }
 
-int bench_mfma_f64(int iters, double* tflops, hipStream_t st) {
+int bench_mfma_f64(int iters, double* tflops, hipStream_t st, int variant) {
   double* sink = nullptr;
-  BIEM_HIPCHK(hipMalloc((void**)&sink, 8));
+  BIEM_HIPCHK(hipMalloc((void**)&sink, 16));
   hipEvent_t e0, e1;
   BIEM_HIPCHK(hipEventCreate(&e0));
   BIEM_HIPCHK(hipEventCreate(&e1));
   const int blocks = 256 * 2;   // 2 workgroups of 4 waves per CU -> 2 waves per SIMD
-  hipLaunchKernelGGL(k_bench_mfma, dim3(blocks), dim3(256), 0, st, 16, sink);   // warm-up
+  auto launch = [&](int n) {
+    if (variant == 1) hipLaunchKernelGGL(k_bench_mfma<1>, dim3(blocks), dim3(256), 0, st, n, sink);
+    else hipLaunchKernelGGL(k_bench_mfma<0>, dim3(blocks), dim3(256), 0, st, n, sink);
+  };
+  launch(16);   // warm-up
   BIEM_HIPCHK(hipEventRecord(e0, st));
-  hipLaunchKernelGGL(k_bench_mfma, dim3(blocks), dim3(256), 0, st, iters, sink);
+  launch(iters);
   BIEM_HIPCHK(hipEventRecord(e1, st));
   BIEM_HIPCHK(hipEventSynchronize(e1));
   float ms = 0.f;
   BIEM_HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-  double flops = (double)blocks * 4.0 * (double)iters * 8.0 * (2.0 * 16 * 16 * 4);
+  const double per_iter = variant == 1 ? 16.0 * (2.0 * 4 * 4 * 4 * 4) : 8.0 * (2.0 * 16 * 16 * 4);
+  double flops = (double)blocks * 4.0 * (double)iters * per_iter;
   *tflops = flops / (ms * 1e-3) / 1e12;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(sink);
   return BIEM_OK;

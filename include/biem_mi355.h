@@ -218,6 +218,10 @@ int biem_profile_end(double* ms /*[9]*/, double* work /*[9]*/, long long* launch
 /* ---- microbenchmarks used by bench.py / DESIGN.md (peak checks, not part of the path) ---- */
 /* issues `iters` dependent-free v_mfma_f64_16x16x4_f64 per wave on every SIMD; returns achieved FLOP/s */
 int biem_bench_mfma_f64(int iters, double* tflops, void* stream);
+/* the same with a choice of instruction: variant 0 v_mfma_f64_16x16x4_f64, variant 1 v_mfma_f64_4x4x4_4b_f64 (the one the trailing
+ * update uses).  What a pure MFMA stream SUSTAINS on the box it runs on (1 MI355X, 2 waves per SIMD, 2-second runs: 47.3 and
+ * 75.3 TFLOP/s) - bench.py reports variant 1 beside the 78.6 TFLOP/s the roofline is priced against */
+int biem_bench_mfma_f64_ex(int iters, int variant, double* tflops, void* stream);
 
 #ifdef __cplusplus
 }
