@@ -386,7 +386,6 @@ def main() -> int:
     # which stays priced against the nominal 78.6 TFLOP/s
     sustained = None
     if rank == 0:
-        import ctypes as C
         tf = C.c_double()
         L.check(lib.biem_bench_mfma_f64_ex(2000000, 1, C.byref(tf), None))
         sustained = tf.value
