@@ -1556,8 +1556,8 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
 // (A-operand[k][i] = U12[k][row i], B-operand[k][c] = U12[k][col c]), which is also exactly what the back substitution reads.
 // So the factorisation works in place on the upper triangle: no column-major panel workspace, no transposing panel load / store,
 // no transposed GEMM epilogue, no separate "U rows from L" pass - a panel is two passes over its strip instead of about six.
-//   k_diag_utu  (one workgroup per system): the 64 x 64 diagonal block: pivots d, U11 = D^{-1/2} (D L11^T), W = I - U11^{-T},
-//               multiplier test inside the block
+//   k_diag_utu_reg (one workgroup per system, defined with the small-system kernel below): the 64 x 64 diagonal block: pivots d,
+//               U11 = D^{-1/2} (D L11^T), W = I - U11^{-T}, multiplier test inside the block
 //   strip:      U12 = U11^{-T} A12 = A12 - W A12 in place on the streaming zgemm (K = 64, B operand = the strip's own rows; the
 //               right-hand-side columns are columns of the strip: forward elimination rides along).  A one-thread-per-column
 //               VALU form with the triangle of U11^{-T} from the scalar cache or LDS was 5x slower (292 vs 53 ms per 256 systems)
@@ -1579,69 +1579,6 @@ __global__ void __launch_bounds__(256) k_absmax_upper(const cplx* __restrict__ A
     for (int c = (i / NB) * NB + threadIdx.x; c < n_pad; c += 256) { const cplx v = As[(size_t)i * lda + c]; m = nan_max(m, sqrt(v.x * v.x + v.y * v.y)); }
   }
   block_max_publish(m, growth + 2 * (size_t)s);
-}
-
-__global__ void __launch_bounds__(256) k_diag_utu(cplx* __restrict__ A, long long lda, long long sys_stride, int j, cplx* __restrict__ Wt,
-                                                   int* __restrict__ info, double rel, unsigned long long* __restrict__ growth) {
-  // elimination and inverse exactly as k_diag_nopiv (row r = tid & 63, part = tid >> 6), on a[c][r] = block column c, row r
-  __shared__ cplx a[NB][NB + 1];
-  __shared__ cplx x[NB][NB + 1];     // x[k][c] = ((D L11^T)^{-1})[k][c]
-  __shared__ cplx red[4][NB];
-  __shared__ cplx ssq[NB];           // s_c = sqrt(d_c)
-  __shared__ int bad;
-  const int s = blockIdx.x, tid = threadIdx.x, r = tid & 63, part = tid >> 6;
-  cplx* Ab = A + (size_t)s * sys_stride + (size_t)j * lda + j;
-  if (tid == 0) bad = 0;
-  for (int rr = part; rr < NB; rr += 4) { a[r][rr] = Ab[(size_t)rr * lda + r]; x[rr][r] = make_double2(0.0, 0.0); }   // lanes along the row: coalesced
-  __syncthreads();
-  for (int c = 0; c < NB; ++c) {
-    const cplx piv = a[c][c];
-    const double pa = fabs(piv.x) + fabs(piv.y);
-    cplx l = make_double2(0.0, 0.0);
-    if (r > c) {
-      const cplx v = a[c][r];
-      if (part == 0 && !(pa >= rel * (fabs(v.x) + fabs(v.y)))) bad = 1;
-      l = cmul(v, crecip(piv));
-      for (int c2 = c + 1 + part; c2 < NB; c2 += 4) a[c2][r] = cfnma(l, a[c2][c], a[c2][r]);
-    } else if (r == c && part == 0 && !(pa > 0.0)) bad = 1;
-    __syncthreads();
-    if (r > c && part == 0) a[c][r] = l;
-  }
-  __syncthreads();
-  for (int d = 0; d < NB; ++d) {
-    const int k = r, c = r + d;
-    cplx acc = make_double2(0.0, 0.0);
-    if (c < NB)
-      for (int m = k + 1 + part; m <= c; m += 4) acc = cfma(a[m][k], x[m][c], acc);
-    red[part][r] = acc;
-    __syncthreads();
-    if (part == 0 && c < NB) {
-      cplx sum = red[0][r];
-      sum.x += red[1][r].x + red[2][r].x + red[3][r].x; sum.y += red[1][r].y + red[2][r].y + red[3][r].y;
-      cplx rhs = (d == 0) ? make_double2(1.0, 0.0) : make_double2(0.0, 0.0);
-      rhs.x -= sum.x; rhs.y -= sum.y;
-      x[k][c] = cmul(rhs, crecip(a[k][k]));
-    }
-    __syncthreads();
-  }
-  if (tid < NB) ssq[tid] = zsqrt(a[tid][tid]);
-  __syncthreads();
-  // U11[rr][c] = (D L11^T)[rr][c] / s_rr for c >= rr, back into the matrix (lanes along the row); growth of the D L^T entries
-  double um = 0.0;
-  for (int rr = part; rr < NB; rr += 4) {
-    const int c = r;
-    if (c >= rr) { const cplx u = a[c][rr]; um = nan_max(um, sqrt(u.x * u.x + u.y * u.y)); Ab[(size_t)rr * lda + c] = cmul(u, crecip(ssq[rr])); }
-  }
-  block_max_publish(um, growth + 2 * (size_t)s + 1);
-  // W = I - X^T, X^T = U11^{-T} (X^T[i][k] = x[k][i] s_i, k <= i), stored [k][i] - the A-operand order of the streaming zgemm, which
-  // then forms the strip in place:  U12 = X^T A12 = A12 - W A12   (lanes along i: coalesced)
-  cplx* Wo = Wt + (size_t)s * NB * NB;
-  for (int k = part; k < NB; k += 4) {
-    cplx w = make_double2(0.0, 0.0);
-    if (k <= r) { const cplx xt = cmul(x[k][r], ssq[r]); w = make_double2((k == r ? 1.0 : 0.0) - xt.x, -xt.y); }
-    Wo[k * NB + r] = w;
-  }
-  if (tid == 0 && bad && info[s] == 0) info[s] = -(j + 1);
 }
 
 // Back substitution of the row form, one launch per 64-row block (bottom up), one 1024-thread workgroup per system:
@@ -1862,6 +1799,88 @@ __global__ void __launch_bounds__(SMALL_THREADS, 4) k_small_utu(cplx* __restrict
   if (tid == 0 && bad_row >= 0 && info[s] == 0) info[s] = -(((n - 1 - bad_row) / NB) * NB + 1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The diagonal 64 x 64 block of a panel, register-resident like k_small_utu (same elimination, same publication of finished
+// rows): lane l of the wave that owns row i holds a_il and, in the second slot, column l of the identity carried through the
+// elimination - [A11 | I] -> [D L^T | L^-1] - so the inverse the strip needs, U11^{-T} = D^{-1/2} L^{-1}, comes out of the lanes
+// that the 64-column matrix block leaves idle.  Replaced an LDS form (64 steps of read-modify-write through LDS with a complex
+// division per thread, then 64 two-barrier steps for the inverse; git history): 125 -> ~50 us per launch of one workgroup per CU
+// (cfg 3: 56.4 -> 49.1 ms per 256-system step for strips + diagonal blocks; cfg 2: 61.9 -> 71.7 k systems/s, same box).
+// Writes U11 into the upper triangle of the block and W = I - U11^{-T} as W[k][i] (the A-operand order of the streaming zgemm).
+// ---------------------------------------------------------------------------------------------
+constexpr int DIAG_LDS_CPLX = 2 * (NB * (NB + 1) / 2) + 2 * NB + NB;          // packed U rows, packed L^-1 rows, multipliers [2][64], 1 / sqrt(d)
+__global__ void __launch_bounds__(SMALL_THREADS) k_diag_utu_reg(cplx* __restrict__ A, long long lda, long long sys_stride, int j,
+                                                                 cplx* __restrict__ Wt, int* __restrict__ info, double rel,
+                                                                 unsigned long long* __restrict__ growth) {
+  extern __shared__ cplx sd[];
+  __shared__ int bad;
+  constexpr int NW = SMALL_THREADS / 64, KR = NB / NW;
+  cplx* su = sd;                                   // (r, c), c >= r, at uoff(r) + c
+  cplx* sy = su + NB * (NB + 1) / 2;               // (i, k), k <= i, at yoff(i) + k
+  cplx* lrow = sy + NB * (NB + 1) / 2;             // [2][64] multipliers a_cj / a_cc of the current row
+  cplx* isq = lrow + 2 * NB;                       // 1 / sqrt(d_r)
+  auto uoff = [](int r) { return r * NB - (r * (r - 1)) / 2 - r; };
+  auto yoff = [](int i) { return (i * (i + 1)) / 2; };
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  cplx* Ab = A + (size_t)s * sys_stride + (size_t)j * lda + j;
+  if (tid == 0) bad = 0;
+  cplx a0[KR], y1[KR];
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+    const int i = w + NW * k;
+    a0[k] = lane >= i ? Ab[(size_t)i * lda + lane] : make_double2(0.0, 0.0);
+    y1[k] = make_double2(lane == i ? 1.0 : 0.0, 0.0);
+  }
+  auto publish = [&](int i, const cplx& r0, const cplx& r1) {
+    cplx d;
+    d.x = __shfl(r0.x, i, 64); d.y = __shfl(r0.y, i, 64);
+    const double rr = 1.0 / (d.x * d.x + d.y * d.y);
+    const cplx ip = make_double2(d.x * rr, -d.y * rr);
+    if (lane >= i) { su[uoff(i) + lane] = r0; lrow[(i & 1) * NB + lane] = cmul(r0, ip); }
+    if (lane <= i) sy[yoff(i) + lane] = r1;
+  };
+  if (w == 0) publish(0, a0[0], y1[0]);
+  double um = 0.0;
+  for (int c = 0; c < NB; ++c) {
+    __syncthreads();                            // row c has been published
+    const cplx* rc = su + uoff(c);
+    const cplx* lr = lrow + (c & 1) * NB;
+    const cplx u0 = rc[lane >= c ? lane : c];
+    cplx u1 = sy[yoff(c) + (lane <= c ? lane : c)];
+    if (lane > c) u1 = make_double2(0.0, 0.0);
+    if (w == ((c + 1 + NW / 2) & (NW - 1))) {   // acceptance tests on row c, once, by a wave that does not publish the next row
+      const cplx piv = rc[c];
+      const double pa = fabs(piv.x) + fabs(piv.y);
+      if ((lane > c && !(pa >= rel * (fabs(u0.x) + fabs(u0.y)))) || !(pa > 0.0)) bad = 1;
+      if (lane >= c) um = nan_max(um, u0.x * u0.x + u0.y * u0.y);
+    }
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const int i = w + NW * k;
+      if (i > c) {
+        const cplx f = lr[i];
+        a0[k] = cfnma(f, u0, a0[k]);
+        y1[k] = cfnma(f, u1, y1[k]);
+        if (i == c + 1) publish(i, a0[k], y1[k]);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < NB) isq[tid] = crecip(zsqrt(su[uoff(tid) + tid]));
+  block_max_publish(sqrt(um), growth + 2 * (size_t)s + 1);       // (its barrier also orders isq)
+  // U11 = D^{-1/2} (D L^T) into the upper triangle of the block (lanes along the row)
+  for (int r = w; r < NB; r += NW)
+    if (lane >= r) Ab[(size_t)r * lda + lane] = cmul(su[uoff(r) + lane], isq[r]);
+  // W[k][i] = delta_ki - (U11^{-T})[i][k] = delta_ki - L^-1[i][k] / sqrt(d_i), k <= i (lanes along i)
+  cplx* Wo = Wt + (size_t)s * NB * NB;
+  for (int k = w; k < NB; k += NW) {
+    cplx v = make_double2(0.0, 0.0);
+    if (k <= lane) { const cplx xt = cmul(sy[yoff(lane) + k], isq[lane]); v = make_double2((k == lane ? 1.0 : 0.0) - xt.x, -xt.y); }
+    Wo[k * NB + lane] = v;
+  }
+  if (tid == 0 && bad && info[s] == 0) info[s] = -(j + 1);
+}
+
 bool sym_small_path(int n_active, int nrhs) { return n_active > 0 && n_active <= SMALL_N_MAX && nrhs <= SMALL_RHS_MAX && !getenv("BIEM_NO_SMALL_PATH"); }
 
 int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_info, void* d_work,
@@ -1915,10 +1934,11 @@ int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long 
   int gemm_rc = BIEM_OK;
   auto gemm = [&](auto&&... a) { const int r = launch_gemm_stream(a...); if (r != BIEM_OK && gemm_rc == BIEM_OK) gemm_rc = r; };
   const bool rhs_gemv = nrhs > 0 && nrhs <= 8;
+  BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_diag_utu_reg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DIAG_LDS_CPLX * sizeof(cplx))));
   auto panel = [&](int j) {
     {
       ProfScope ps(PK_PANEL, st, 0.0);
-      hipLaunchKernelGGL(k_diag_utu, dim3(nb), dim3(256), 0, st, A, lda, sys_stride, j, Wt, d_info, nopiv, growth);
+      hipLaunchKernelGGL(k_diag_utu_reg, dim3(nb), dim3(SMALL_THREADS), DIAG_LDS_CPLX * sizeof(cplx), st, A, lda, sys_stride, j, Wt, d_info, nopiv, growth);
     }
     // A operand W[k][i], i = row - j: the base shifted by -j rows (only rows j .. j+63 are addressed)
     if (n_cols > j + NB)
