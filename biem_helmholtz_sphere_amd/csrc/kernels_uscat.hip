@@ -131,6 +131,137 @@ __global__ void __launch_bounds__(256) k_uscat(int tree, int d, int H, int n_end
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Near field, kind = "outer", trees a (2-D) and ba (3-D; bpa is ba in permuted axes): ONE POINT PER LANE.
+// The generic kernel above spends one workgroup per (point, system), evaluates every harmonic from scratch (an O(n) Legendre
+// recurrence and a sin / cos per harmonic) and leaves 63 lanes idle while lane 0 runs the radial recurrences: 2.0e6
+// point-systems/s at cfg 3 (16 balls, H = 400) - the 100 x 100 plot grid of the reference's second hot loop took as long as the
+// solve.  Here a lane owns a point and walks the harmonics by recurrence, all in registers:
+//   h_n(k r): upward three-term recurrence from h_0, h_1 (the outgoing function is the dominant solution: stable), restarted
+//             for every order m (n_end^2 / 2 extra steps - cheaper than an n_end-entry array per lane);
+//   Pbar_n^m: the normalised recurrence of pbar_single with its square-root coefficients tabulated once per workgroup in LDS;
+//   e^{i m phi}: rotation by (cos phi, sin phi) = (u1, u2) / |(u1, u2)| - no trigonometric call at all;
+//   the +m and -m harmonics of a degree share Pbar and h;  the ball's coefficients c[h] = density * blc sit in LDS in (n, m)
+//   order (every lane reads the same entry: a broadcast).
+// ---------------------------------------------------------------------------------------------
+constexpr int kFastNendMax3 = 48;          // LDS: 2 n_end^2 doubles of recurrence coefficients + n_end^2 complex of c
+constexpr int kFastNendMax2 = kMaxRadU;    // 2-D: 2 n_end - 1 complex of c
+template <int TREE>
+__global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, const int* __restrict__ labels, int nb, int B, int P,
+                                                     const cplx* __restrict__ k, const double* __restrict__ centers,
+                                                     const double* __restrict__ radii, int geom_batched, const cplx* __restrict__ c,
+                                                     const double* __restrict__ pts, int flags, cplx* __restrict__ out) {
+  extern __shared__ double sfast[];
+  // 3-D: ra[q * n_end + m], rb[q * n_end + m] (q > m), cm[m]; then the ball's coefficients sC[pos]
+  double* ra = sfast;
+  double* rb = ra + (TREE == TREE_BA ? n_end * n_end : 0);
+  double* cmm = rb + (TREE == TREE_BA ? n_end * n_end : 0);
+  cplx* sC = (cplx*)(cmm + (TREE == TREE_BA ? ((n_end + 1) & ~1) : 0));
+  const int s = blockIdx.y, tid = threadIdx.x;
+  const int p = blockIdx.x * 256 + tid, pc = p < P ? p : P - 1;
+  const bool per_ball = (flags & BIEM_USCAT_PER_BALL) != 0, pb = (flags & BIEM_USCAT_POINTS_BATCHED) != 0;
+  if (TREE == TREE_BA) {
+    for (int e = tid; e < n_end * n_end; e += 256) {
+      const int q = e / n_end, m = e - q * n_end;
+      double a = 0.0, b = 0.0;
+      if (q > m) {
+        a = sqrt((double)(4 * q * q - 1) / (double)(q * q - m * m));
+        b = sqrt((double)((q - 1) * (q - 1) - m * m) / (double)(4 * (q - 1) * (q - 1) - 1));
+      }
+      ra[e] = a; rb[e] = b;
+    }
+    for (int m = tid; m < n_end; m += 256) cmm[m] = m == 0 ? 0.0 : sqrt((double)(2 * m + 1) / (double)(2 * m));
+  }
+  double x[3];
+  for (int i = 0; i < d; ++i) x[i] = pb ? pts[((size_t)i * P + pc) * nb + s] : pts[(size_t)i * P + pc];
+  const cplx kk = k[s];
+  bool bad = false;
+  double tr = 0.0, ti = 0.0;
+  const double dd2 = (double)(d - 2);
+  for (int b = 0; b < B; ++b) {
+    __syncthreads();                       // the previous ball's coefficients are no longer read (and the tables are written)
+    const cplx* cs = c + ((size_t)s * B + b) * H;
+    for (int h = tid; h < H; h += 256) {
+      int pos;
+      if (TREE == TREE_BA) { const int n = labels[3 * h], m = labels[3 * h + 1]; pos = n * n + n + m; }
+      else pos = labels[3 * h] + n_end - 1;
+      sC[pos] = cs[h];
+    }
+    __syncthreads();
+    const double* cb = centers + ((geom_batched ? (size_t)s * B : 0) + b) * d;
+    const double rho = radii[(geom_batched ? (size_t)s * B : 0) + b];
+    double u[3] = {0.0, 0.0, 0.0}, r2 = 0.0;
+    for (int i = 0; i < d; ++i) { u[i] = x[i] - cb[i]; r2 += u[i] * u[i]; }
+    const double r = sqrt(r2);
+    if (r < rho) bad = true;
+    // h_0, h_1 at k r (r = 0 only inside a ball: the value is discarded)
+    zc J2[4], H2[4];
+    radial_jh(d, 1, cscale(kk, r > 0.0 ? r : rho), J2, H2);
+    const cplx h0 = H2[0], h1 = H2[1];
+    const cplx ix = crecip(cscale(kk, r > 0.0 ? r : rho));
+    double ar = 0.0, ai = 0.0;
+    if (TREE == TREE_A) {
+      // Y_m = e^{i m theta} / sqrt(2 pi); degree n = |m|
+      const double e1x = r > 0.0 ? u[0] / r : 1.0, e1y = r > 0.0 ? u[1] / r : 0.0;
+      double ex = 1.0, ey = 0.0;
+      cplx hp = h0, hc = h1;               // h_n, h_{n+1}
+      for (int n = 0; n < n_end; ++n) {
+        const cplx cp = sC[n_end - 1 + n];
+        cplx t = make_double2(cp.x * ex - cp.y * ey, cp.x * ey + cp.y * ex);
+        if (n > 0) { const cplx cn = sC[n_end - 1 - n]; t.x += cn.x * ex + cn.y * ey; t.y += cn.y * ex - cn.x * ey; }
+        ar += hp.x * t.x - hp.y * t.y; ai += hp.x * t.y + hp.y * t.x;
+        const cplx f = cscale(ix, 2.0 * n + dd2 + 2.0);            // (2 (n + 1) + d - 2) / x with d = 2: h_{n+2} = (2 (n + 1) / x) h_{n+1} - h_n
+        const cplx hn = csub(cmul(f, hc), hp);
+        hp = hc; hc = hn;
+        const double nx = ex * e1x - ey * e1y; ey = ex * e1y + ey * e1x; ex = nx;
+      }
+    } else {
+      const double rxy = sqrt(u[1] * u[1] + u[2] * u[2]);
+      const double c0 = r > 0.0 ? u[0] / r : 1.0, s0 = r > 0.0 ? rxy / r : 0.0;
+      const double e1x = rxy > 0.0 ? u[1] / rxy : 1.0, e1y = rxy > 0.0 ? u[2] / rxy : 0.0;
+      double ex = 1.0, ey = 0.0, pmm = 0.70710678118654752440;
+      cplx hm = h0, hm1 = h1;              // h_m, h_{m+1}: advanced by one per order m
+      for (int m = 0; m < n_end; ++m) {
+        if (m > 0) {
+          pmm *= cmm[m] * s0;
+          const cplx f = cscale(ix, 2.0 * m + dd2);                  // h_{m+1} = ((2 m + d - 2) / x) h_m - h_{m-1}
+          const cplx hn = csub(cmul(f, hm1), hm);
+          hm = hm1; hm1 = hn;
+          const double nx = ex * e1x - ey * e1y; ey = ex * e1y + ey * e1x; ex = nx;
+        }
+        cplx hp = hm, hc = hm1;            // h_n, h_{n+1} for n = m ..
+        double p0 = 0.0, p1 = pmm;
+        double sr = 0.0, si = 0.0;         // sum over n of h_n Pbar_n^m c_{n, +-m} (the e^{+- i m phi} factors applied once per m)
+        double qr = 0.0, qi = 0.0;
+        for (int n = m; n < n_end; ++n) {
+          const cplx cp = sC[n * n + n + m];
+          const double wr = hp.x * p1, wi = hp.y * p1;
+          sr += wr * cp.x - wi * cp.y; si += wr * cp.y + wi * cp.x;
+          if (m > 0) { const cplx cn = sC[n * n + n - m]; qr += wr * cn.x - wi * cn.y; qi += wr * cn.y + wi * cn.x; }
+          const int q = n + 1;
+          if (q < n_end) {
+            const double p2 = ra[q * n_end + m] * (c0 * p1 - rb[q * n_end + m] * p0);
+            p0 = p1; p1 = p2;
+            const cplx f = cscale(ix, 2.0 * q + dd2);              // h_{q+1} = ((2 q + d - 2) / x) h_q - h_{q-1}
+            const cplx hn = csub(cmul(f, hc), hp);
+            hp = hc; hc = hn;
+          }
+        }
+        ar += sr * ex - si * ey + qr * ex + qi * ey;
+        ai += sr * ey + si * ex + qi * ex - qr * ey;
+      }
+    }
+    ar *= kInvSqrt2Pi; ai *= kInvSqrt2Pi;
+    if (per_ball) { if (p < P) out[((size_t)p * nb + s) * B + b] = make_double2(ar, ai); }
+    else { tr += ar; ti += ai; }
+  }
+  const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+  if (p >= P) return;
+  if (per_ball) {
+    if (bad) for (int b = 0; b < B; ++b) out[((size_t)p * nb + s) * B + b] = make_double2(qnan, qnan);
+  } else out[(size_t)p * nb + s] = bad ? make_double2(qnan, qnan) : make_double2(tr, ti);
+}
+
 int launch_uscat(const biem_plan* p, int nb, int B, int P, const double* d_k, const double* d_eta, const double* d_centers,
                  const double* d_radii, int geom_batched, const double* d_density, const double* d_points, int flags,
                  double* d_out, void* d_work, size_t work_bytes, hipStream_t st) {
@@ -143,6 +274,23 @@ int launch_uscat(const biem_plan* p, int nb, int B, int P, const double* d_k, co
                      (flags & BIEM_USCAT_KIND_INNER) && !(flags & BIEM_USCAT_FAR_FIELD) ? 1 : 0, (const cplx*)d_k, d_eta, d_radii,
                      geom_batched, (const cplx*)d_density, c);
   BIEM_LAUNCHCHK();
+  const bool near_outer = !(flags & BIEM_USCAT_FAR_FIELD) && !(flags & BIEM_USCAT_KIND_INNER);
+  if (near_outer && !getenv("BIEM_USCAT_GENERIC") && nb <= 65535 &&
+      ((p->tree == TREE_BA && p->n_end <= kFastNendMax3) || (p->tree == TREE_A && p->n_end <= kFastNendMax2))) {
+    const int ne = p->n_end;
+    if (p->tree == TREE_BA) {
+      const size_t shm = (size_t)(2 * ne * ne + ((ne + 1) & ~1)) * sizeof(double) + (size_t)ne * ne * sizeof(cplx);
+      BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_uscat_fast<TREE_BA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+      hipLaunchKernelGGL(k_uscat_fast<TREE_BA>, dim3((P + 255) / 256, nb), dim3(256), shm, st, p->d, p->H, ne, p->d_labels, nb, B, P,
+                         (const cplx*)d_k, d_centers, d_radii, geom_batched, (const cplx*)c, d_points, flags, (cplx*)d_out);
+    } else {
+      const size_t shm = (size_t)(2 * ne - 1) * sizeof(cplx);
+      hipLaunchKernelGGL(k_uscat_fast<TREE_A>, dim3((P + 255) / 256, nb), dim3(256), shm, st, p->d, p->H, ne, p->d_labels, nb, B, P,
+                         (const cplx*)d_k, d_centers, d_radii, geom_batched, (const cplx*)c, d_points, flags, (cplx*)d_out);
+    }
+    BIEM_LAUNCHCHK();
+    return BIEM_OK;
+  }
   hipLaunchKernelGGL(k_uscat, dim3(P, nb), dim3(256), (size_t)B * sizeof(cplx), st, p->tree, p->d, p->H, p->n_end, p->d_labels,
                      p->d_deg, nb, B, P, (const cplx*)d_k, d_centers, d_radii, geom_batched, (const cplx*)c, d_points, flags, (cplx*)d_out);
   BIEM_LAUNCHCHK();

@@ -527,6 +527,39 @@ def test_small_systems_one_launch_path(amd, bt, d, n_end, B, monkeypatch):
         assert np.max(np.abs(u_small[:, i] - ref)) < 1e-10 * np.max(np.abs(ref)), i
 
 
+@pytest.mark.parametrize("bt,d,n_end,B", [("ba", 3, 7, 3), ("a", 2, 11, 4), ("bpa", 3, 5, 2), ("ba", 3, 20, 2)])
+def test_uscat_point_per_lane_matches_generic(amd, bt, d, n_end, B, monkeypatch):
+    """Near-field evaluation for kind = "outer" on trees a / ba / bpa runs one point per lane with recurrences for h_n, Pbar_n^m and
+    e^{i m phi} (k_uscat_fast); BIEM_USCAT_GENERIC=1 forces the harmonic-by-harmonic kernel.  Same results (1e-12), incl. per_ball,
+    points given per system, complex k, NaN inside the balls and a point count that is not a multiple of the workgroup size."""
+    c = amd.create_from_branching_types(bt)
+    rng = np.random.default_rng(n_end + B)
+    cen = np.zeros((B, d)); cen[:, 0] = 2.7 * np.arange(B); cen[:, 1:] = 0.4 * rng.normal(size=(B, d - 1))
+    rad = 0.6 + 0.4 * rng.random(B)
+    ks = np.array([0.8, 1.9 + 0.2j, 3.1])
+    dirs = np.zeros((d, len(ks))); dirs[1] = 1.0
+    uin, _ = amd.plane_wave(k=_dev(ks, torch.complex128), direction=_dev(dirs))
+    calc = amd.biem(c, centers=_dev(cen)[None], radii=_dev(rad)[None], k=_dev(ks, torch.complex128), n_end=n_end, uin=uin)
+    x = 4.0 * rng.normal(size=(333, d)); x[:, 0] += 2.0
+    x[0] = cen[0] + 0.3 * rad[0] * np.eye(d)[0]                       # inside ball 0 -> NaN
+    x[1] = cen[B - 1] + 1.0000001 * rad[B - 1] * np.eye(d)[1]         # just outside
+    xs = np.repeat(x[:, :, None], len(ks), axis=2) + 0.01 * np.arange(len(ks))   # [P, d, K] per-system points
+    xs[0] = x[0][:, None]
+
+    def run():
+        return (calc.uscat(_dev(x.T)).cpu().numpy(), calc.uscat(_dev(x.T), per_ball=True).cpu().numpy(),
+                calc.uscat(_dev(np.transpose(xs, (1, 0, 2))), expand_x=False).cpu().numpy())
+
+    fast = run()
+    monkeypatch.setenv("BIEM_USCAT_GENERIC", "1")
+    gen = run()
+    for f, g in zip(fast, gen):
+        assert f.shape == g.shape
+        assert np.array_equal(np.isnan(f.real), np.isnan(g.real)) and np.isnan(f[0]).all() and not np.isnan(f[1]).any()
+        ok = ~np.isnan(g.real)
+        assert np.max(np.abs(f[ok] - g[ok])) < 1e-12 * np.max(np.abs(g[ok]))
+
+
 @pytest.mark.parametrize("force_lu_fallback", [False, True])
 def test_batched_geometry_and_points_per_system(amd, force_lu_fallback, monkeypatch):
     """(force_lu_fallback: every system is rejected by the symmetric path and re-solved by the pivoted LU from gathered
