@@ -132,7 +132,8 @@ __global__ void __launch_bounds__(256) k_uscat(int tree, int d, int H, int n_end
 }
 
 // ---------------------------------------------------------------------------------------------
-// Near field, kind = "outer", trees a (2-D) and ba (3-D; bpa is ba in permuted axes): ONE POINT PER LANE.
+// Near field of kind = "outer" and the far field, trees a (2-D), ba (3-D; bpa is ba in permuted axes) and bba (4-D; bpbpa
+// likewise): ONE POINT PER LANE.
 // The generic kernel above spends one workgroup per (point, system), evaluates every harmonic from scratch (an O(n) Legendre
 // recurrence and a sin / cos per harmonic) and leaves 63 lanes idle while lane 0 runs the radial recurrences: 2.0e6
 // point-systems/s at cfg 3 (16 balls, H = 400) - the 100 x 100 plot grid of the reference's second hot loop took as long as the
@@ -146,21 +147,26 @@ __global__ void __launch_bounds__(256) k_uscat(int tree, int d, int H, int n_end
 // ---------------------------------------------------------------------------------------------
 constexpr int kFastNendMax3 = 48;          // LDS: 2 n_end^2 doubles of recurrence coefficients + n_end^2 complex of c
 constexpr int kFastNendMax2 = kMaxRadU;    // 2-D: 2 n_end - 1 complex of c
-template <int TREE>
+constexpr int kFastNendMax4 = 14;          // 4-D (bba): c in a dense [n][l][m] store, n_end^2 (2 n_end - 1) complex = 85 KB at 14
+template <int TREE, bool FAR>
 __global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, const int* __restrict__ labels, int nb, int B, int P,
                                                      const cplx* __restrict__ k, const double* __restrict__ centers,
                                                      const double* __restrict__ radii, int geom_batched, const cplx* __restrict__ c,
                                                      const double* __restrict__ pts, int flags, cplx* __restrict__ out) {
   extern __shared__ double sfast[];
   // 3-D: ra[q * n_end + m], rb[q * n_end + m] (q > m), cm[m]; then the ball's coefficients sC[pos]
+  constexpr bool LEG = TREE == TREE_BA || TREE == TREE_BBA;       // a Legendre factor Pbar_l^m
   double* ra = sfast;
-  double* rb = ra + (TREE == TREE_BA ? n_end * n_end : 0);
-  double* cmm = rb + (TREE == TREE_BA ? n_end * n_end : 0);
-  cplx* sC = (cplx*)(cmm + (TREE == TREE_BA ? ((n_end + 1) & ~1) : 0));
+  double* rb = ra + (LEG ? n_end * n_end : 0);
+  double* cmm = rb + (LEG ? n_end * n_end : 0);
+  double* ga = cmm + (LEG ? ((n_end + 1) & ~1) : 0);              // bba: Gegenbauer a_q of order lam = l + 1 at [l * n_end + q]
+  double* gia = ga + (TREE == TREE_BBA ? n_end * n_end : 0);       //      1 / a_q
+  double* g0 = gia + (TREE == TREE_BBA ? n_end * n_end : 0);       //      p_0 = 1 / sqrt(h_0(l))
+  cplx* sC = (cplx*)(g0 + (TREE == TREE_BBA ? ((n_end + 1) & ~1) : 0));
   const int s = blockIdx.y, tid = threadIdx.x;
   const int p = blockIdx.x * 256 + tid, pc = p < P ? p : P - 1;
   const bool per_ball = (flags & BIEM_USCAT_PER_BALL) != 0, pb = (flags & BIEM_USCAT_POINTS_BATCHED) != 0;
-  if (TREE == TREE_BA) {
+  if (LEG) {
     for (int e = tid; e < n_end * n_end; e += 256) {
       const int q = e / n_end, m = e - q * n_end;
       double a = 0.0, b = 0.0;
@@ -172,7 +178,20 @@ __global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, con
     }
     for (int m = tid; m < n_end; m += 256) cmm[m] = m == 0 ? 0.0 : sqrt((double)(2 * m + 1) / (double)(2 * m));
   }
-  double x[3];
+  if (TREE == TREE_BBA) {                   // the coefficients of gbar_single
+    for (int e = tid; e < n_end * n_end; e += 256) {
+      const int l = e / n_end, q = e - l * n_end;
+      const double lam = (double)(l + 1);
+      const double aq = q == 0 ? 1.0 : 0.5 * sqrt((double)q * ((double)q + 2.0 * lam - 1.0) / (((double)q + lam - 1.0) * ((double)q + lam)));
+      ga[e] = q == 0 ? 0.0 : aq; gia[e] = 1.0 / aq;
+    }
+    for (int l = tid; l < n_end; l += 256) {
+      double h0 = 0.5 * kPi;
+      for (int i = 1; i <= l; ++i) h0 *= ((double)i + 0.5) / ((double)i + 1.0);
+      g0[l] = 1.0 / sqrt(h0);
+    }
+  }
+  double x[4];
   for (int i = 0; i < d; ++i) x[i] = pb ? pts[((size_t)i * P + pc) * nb + s] : pts[(size_t)i * P + pc];
   const cplx kk = k[s];
   bool bad = false;
@@ -184,21 +203,31 @@ __global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, con
     for (int h = tid; h < H; h += 256) {
       int pos;
       if (TREE == TREE_BA) { const int n = labels[3 * h], m = labels[3 * h + 1]; pos = n * n + n + m; }
+      else if (TREE == TREE_BBA) pos = (labels[3 * h] * n_end + labels[3 * h + 1]) * (2 * n_end - 1) + labels[3 * h + 2] + n_end - 1;
       else pos = labels[3 * h] + n_end - 1;
       sC[pos] = cs[h];
     }
     __syncthreads();
     const double* cb = centers + ((geom_batched ? (size_t)s * B : 0) + b) * d;
     const double rho = radii[(geom_batched ? (size_t)s * B : 0) + b];
-    double u[3] = {0.0, 0.0, 0.0}, r2 = 0.0;
+    double u[4] = {0.0, 0.0, 0.0, 0.0}, r2 = 0.0;
     for (int i = 0; i < d; ++i) { u[i] = x[i] - cb[i]; r2 += u[i] * u[i]; }
     const double r = sqrt(r2);
-    if (r < rho) bad = true;
-    // h_0, h_1 at k r (r = 0 only inside a ball: the value is discarded)
-    zc J2[4], H2[4];
-    radial_jh(d, 1, cscale(kk, r > 0.0 ? r : rho), J2, H2);
-    const cplx h0 = H2[0], h1 = H2[1];
-    const cplx ix = crecip(cscale(kk, r > 0.0 ? r : rho));
+    if (!FAR && r < rho) bad = true;
+    // h_0, h_1 at k r (r = 0 only inside a ball: the value is discarded).  Far field: the radial factor is (-i)^n, i.e. the
+    // "recurrence" h_{n+1} = -i h_n from h_0 = 1 (advance() below)
+    cplx h0 = make_double2(1.0, 0.0), h1 = make_double2(0.0, -1.0), ix = make_double2(0.0, 0.0);
+    if (!FAR) {
+      zc J2[4], H2[4];
+      radial_jh(d, 1, cscale(kk, r > 0.0 ? r : rho), J2, H2);
+      h0 = H2[0]; h1 = H2[1];
+      ix = crecip(cscale(kk, r > 0.0 ? r : rho));
+    }
+    // next of (h_{q-1}, h_q): h_{q+1} = ((2 q + d - 2) / x) h_q - h_{q-1}
+    auto advance = [&](const cplx& hprev, const cplx& hcur, double two_q) -> cplx {
+      if (FAR) return make_double2(hcur.y, -hcur.x);
+      return csub(cmul(cscale(ix, two_q + dd2), hcur), hprev);
+    };
     double ar = 0.0, ai = 0.0;
     if (TREE == TREE_A) {
       // Y_m = e^{i m theta} / sqrt(2 pi); degree n = |m|
@@ -210,10 +239,60 @@ __global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, con
         cplx t = make_double2(cp.x * ex - cp.y * ey, cp.x * ey + cp.y * ex);
         if (n > 0) { const cplx cn = sC[n_end - 1 - n]; t.x += cn.x * ex + cn.y * ey; t.y += cn.y * ex - cn.x * ey; }
         ar += hp.x * t.x - hp.y * t.y; ai += hp.x * t.y + hp.y * t.x;
-        const cplx f = cscale(ix, 2.0 * n + dd2 + 2.0);            // (2 (n + 1) + d - 2) / x with d = 2: h_{n+2} = (2 (n + 1) / x) h_{n+1} - h_n
-        const cplx hn = csub(cmul(f, hc), hp);
+        const cplx hn = advance(hp, hc, 2.0 * n + 2.0);
         hp = hc; hc = hn;
         const double nx = ex * e1x - ey * e1y; ey = ex * e1y + ey * e1x; ex = nx;
+      }
+    } else if (TREE == TREE_BBA) {
+      // Y_{n l m} = s0^l g_{n-l}^{(l+1)}(c0) Pbar_l^{|m|}(c1) e^{i m phi} / sqrt(2 pi): three nested recurrences; (h_m, h_{m+1})
+      // runs along m, (h_l, h_{l+1}) along l from it, (h_n, h_{n+1}) along n from that - no restart from h_0
+      const double rho2 = sqrt(u[2] * u[2] + u[3] * u[3]), rho1 = sqrt(u[1] * u[1] + rho2 * rho2);
+      const double c0 = r > 0.0 ? u[0] / r : 1.0, s0 = r > 0.0 ? rho1 / r : 0.0;
+      const double c1 = rho1 > 0.0 ? u[1] / rho1 : 1.0, s1 = rho1 > 0.0 ? rho2 / rho1 : 0.0;
+      const double e1x = rho2 > 0.0 ? u[2] / rho2 : 1.0, e1y = rho2 > 0.0 ? u[3] / rho2 : 0.0;
+      const int mstride = 2 * n_end - 1;
+      double ex = 1.0, ey = 0.0, pmm = 0.70710678118654752440, s0m = 1.0;
+      cplx hm = h0, hm1 = h1;
+      for (int m = 0; m < n_end; ++m) {
+        if (m > 0) {
+          pmm *= cmm[m] * s1; s0m *= s0;
+          const cplx hn = advance(hm, hm1, 2.0 * m);
+          hm = hm1; hm1 = hn;
+          const double nx = ex * e1x - ey * e1y; ey = ex * e1y + ey * e1x; ex = nx;
+        }
+        double p0 = 0.0, p1 = pmm, sl = s0m;
+        cplx hl = hm, hl1 = hm1;
+        double sr = 0.0, si = 0.0, qr = 0.0, qi = 0.0;
+        for (int l = m; l < n_end; ++l) {
+          double gp0 = 0.0, gp1 = g0[l];
+          cplx hp = hl, hc = hl1;
+          const double alm = sl * p1;
+          for (int n = l; n < n_end; ++n) {
+            const double amp = alm * gp1;
+            const double wr = hp.x * amp, wi = hp.y * amp;
+            const cplx* cc = sC + (n * n_end + l) * mstride + n_end - 1;
+            const cplx cp = cc[m];
+            sr += wr * cp.x - wi * cp.y; si += wr * cp.y + wi * cp.x;
+            if (m > 0) { const cplx cn = cc[-m]; qr += wr * cn.x - wi * cn.y; qi += wr * cn.y + wi * cn.x; }
+            const int q = n - l + 1;
+            if (n + 1 < n_end) {
+              const double gp2 = (c0 * gp1 - ga[l * n_end + q - 1] * gp0) * gia[l * n_end + q];
+              gp0 = gp1; gp1 = gp2;
+              const cplx hn = advance(hp, hc, 2.0 * (n + 1));
+              hp = hc; hc = hn;
+            }
+          }
+          const int ql = l + 1;
+          if (ql < n_end) {
+            const double p2 = ra[ql * n_end + m] * (c1 * p1 - rb[ql * n_end + m] * p0);
+            p0 = p1; p1 = p2;
+            sl *= s0;
+            const cplx hn = advance(hl, hl1, 2.0 * ql);
+            hl = hl1; hl1 = hn;
+          }
+        }
+        ar += sr * ex - si * ey + qr * ex + qi * ey;
+        ai += sr * ey + si * ex + qi * ex - qr * ey;
       }
     } else {
       const double rxy = sqrt(u[1] * u[1] + u[2] * u[2]);
@@ -224,8 +303,7 @@ __global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, con
       for (int m = 0; m < n_end; ++m) {
         if (m > 0) {
           pmm *= cmm[m] * s0;
-          const cplx f = cscale(ix, 2.0 * m + dd2);                  // h_{m+1} = ((2 m + d - 2) / x) h_m - h_{m-1}
-          const cplx hn = csub(cmul(f, hm1), hm);
+          const cplx hn = advance(hm, hm1, 2.0 * m);
           hm = hm1; hm1 = hn;
           const double nx = ex * e1x - ey * e1y; ey = ex * e1y + ey * e1x; ex = nx;
         }
@@ -242,8 +320,7 @@ __global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, con
           if (q < n_end) {
             const double p2 = ra[q * n_end + m] * (c0 * p1 - rb[q * n_end + m] * p0);
             p0 = p1; p1 = p2;
-            const cplx f = cscale(ix, 2.0 * q + dd2);              // h_{q+1} = ((2 q + d - 2) / x) h_q - h_{q-1}
-            const cplx hn = csub(cmul(f, hc), hp);
+            const cplx hn = advance(hp, hc, 2.0 * q);
             hp = hc; hc = hn;
           }
         }
@@ -252,6 +329,15 @@ __global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, con
       }
     }
     ar *= kInvSqrt2Pi; ai *= kInvSqrt2Pi;
+    if (FAR) {
+      // e^{-i k x.c_b} / (i k)^{(d-1)/2}, as in the generic kernel
+      double xc = 0.0;
+      for (int i = 0; i < d; ++i) xc += x[i] * cb[i];
+      const double pw = 0.5 * (d - 1);
+      const cplx lik = zlog(make_double2(-kk.y, kk.x));
+      const cplx v = cmul(make_double2(ar, ai), zexp(make_double2(kk.y * xc - pw * lik.x, -kk.x * xc - pw * lik.y)));
+      ar = v.x; ai = v.y;
+    }
     if (per_ball) { if (p < P) out[((size_t)p * nb + s) * B + b] = make_double2(ar, ai); }
     else { tr += ar; ti += ai; }
   }
@@ -274,19 +360,29 @@ int launch_uscat(const biem_plan* p, int nb, int B, int P, const double* d_k, co
                      (flags & BIEM_USCAT_KIND_INNER) && !(flags & BIEM_USCAT_FAR_FIELD) ? 1 : 0, (const cplx*)d_k, d_eta, d_radii,
                      geom_batched, (const cplx*)d_density, c);
   BIEM_LAUNCHCHK();
-  const bool near_outer = !(flags & BIEM_USCAT_FAR_FIELD) && !(flags & BIEM_USCAT_KIND_INNER);
-  if (near_outer && !getenv("BIEM_USCAT_GENERIC") && nb <= 65535 &&
-      ((p->tree == TREE_BA && p->n_end <= kFastNendMax3) || (p->tree == TREE_A && p->n_end <= kFastNendMax2))) {
+  // (the far field does not depend on the kind; the near field of kind inner needs j_n: the generic kernel)
+  const bool far = (flags & BIEM_USCAT_FAR_FIELD) != 0;
+  const bool fast_ok = far || !(flags & BIEM_USCAT_KIND_INNER);
+  if (fast_ok && !getenv("BIEM_USCAT_GENERIC") && nb <= 65535 &&
+      ((p->tree == TREE_BA && p->n_end <= kFastNendMax3) || (p->tree == TREE_A && p->n_end <= kFastNendMax2) ||
+       (p->tree == TREE_BBA && p->n_end <= kFastNendMax4))) {
     const int ne = p->n_end;
     if (p->tree == TREE_BA) {
       const size_t shm = (size_t)(2 * ne * ne + ((ne + 1) & ~1)) * sizeof(double) + (size_t)ne * ne * sizeof(cplx);
-      BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_uscat_fast<TREE_BA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-      hipLaunchKernelGGL(k_uscat_fast<TREE_BA>, dim3((P + 255) / 256, nb), dim3(256), shm, st, p->d, p->H, ne, p->d_labels, nb, B, P,
-                         (const cplx*)d_k, d_centers, d_radii, geom_batched, (const cplx*)c, d_points, flags, (cplx*)d_out);
+#define BIEM_USCAT_FAST(TREE, FARF)                                                                                             \
+  {                                                                                                                              \
+    BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_uscat_fast<TREE, FARF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+    hipLaunchKernelGGL((k_uscat_fast<TREE, FARF>), dim3((P + 255) / 256, nb), dim3(256), shm, st, p->d, p->H, ne, p->d_labels, nb, \
+                       B, P, (const cplx*)d_k, d_centers, d_radii, geom_batched, (const cplx*)c, d_points, flags, (cplx*)d_out); \
+  }
+      if (far) BIEM_USCAT_FAST(TREE_BA, true) else BIEM_USCAT_FAST(TREE_BA, false)
+    } else if (p->tree == TREE_BBA) {
+      const size_t shm = (size_t)(4 * ne * ne + 2 * ((ne + 1) & ~1)) * sizeof(double) + (size_t)ne * ne * (2 * ne - 1) * sizeof(cplx);
+      if (far) BIEM_USCAT_FAST(TREE_BBA, true) else BIEM_USCAT_FAST(TREE_BBA, false)
     } else {
       const size_t shm = (size_t)(2 * ne - 1) * sizeof(cplx);
-      hipLaunchKernelGGL(k_uscat_fast<TREE_A>, dim3((P + 255) / 256, nb), dim3(256), shm, st, p->d, p->H, ne, p->d_labels, nb, B, P,
-                         (const cplx*)d_k, d_centers, d_radii, geom_batched, (const cplx*)c, d_points, flags, (cplx*)d_out);
+      if (far) BIEM_USCAT_FAST(TREE_A, true) else BIEM_USCAT_FAST(TREE_A, false)
+#undef BIEM_USCAT_FAST
     }
     BIEM_LAUNCHCHK();
     return BIEM_OK;

@@ -527,10 +527,10 @@ def test_small_systems_one_launch_path(amd, bt, d, n_end, B, monkeypatch):
         assert np.max(np.abs(u_small[:, i] - ref)) < 1e-10 * np.max(np.abs(ref)), i
 
 
-@pytest.mark.parametrize("bt,d,n_end,B", [("ba", 3, 7, 3), ("a", 2, 11, 4), ("bpa", 3, 5, 2), ("ba", 3, 20, 2)])
+@pytest.mark.parametrize("bt,d,n_end,B", [("ba", 3, 7, 3), ("a", 2, 11, 4), ("bpa", 3, 5, 2), ("ba", 3, 20, 2), ("bba", 4, 6, 3), ("bpbpa", 4, 5, 2), ("bba", 4, 10, 2)])
 def test_uscat_point_per_lane_matches_generic(amd, bt, d, n_end, B, monkeypatch):
-    """Near-field evaluation for kind = "outer" on trees a / ba / bpa runs one point per lane with recurrences for h_n, Pbar_n^m and
-    e^{i m phi} (k_uscat_fast); BIEM_USCAT_GENERIC=1 forces the harmonic-by-harmonic kernel.  Same results (1e-12), incl. per_ball,
+    """Near-field evaluation for kind = "outer" and the far field on trees a / ba / bpa / bba / bpbpa run one point per lane with recurrences for
+    h_n, Pbar_n^m and e^{i m phi} (k_uscat_fast); BIEM_USCAT_GENERIC=1 forces the harmonic-by-harmonic kernel.  Same results (1e-12), incl. per_ball,
     points given per system, complex k, NaN inside the balls and a point count that is not a multiple of the workgroup size."""
     c = amd.create_from_branching_types(bt)
     rng = np.random.default_rng(n_end + B)
@@ -548,16 +548,21 @@ def test_uscat_point_per_lane_matches_generic(amd, bt, d, n_end, B, monkeypatch)
 
     def run():
         return (calc.uscat(_dev(x.T)).cpu().numpy(), calc.uscat(_dev(x.T), per_ball=True).cpu().numpy(),
-                calc.uscat(_dev(np.transpose(xs, (1, 0, 2))), expand_x=False).cpu().numpy())
+                calc.uscat(_dev(np.transpose(xs, (1, 0, 2))), expand_x=False).cpu().numpy(),
+                calc.uscat(_dev(x.T), far_field=True).cpu().numpy(), calc.uscat(_dev(x.T), far_field=True, per_ball=True).cpu().numpy())
 
     fast = run()
     monkeypatch.setenv("BIEM_USCAT_GENERIC", "1")
     gen = run()
-    for f, g in zip(fast, gen):
+    for i, (f, g) in enumerate(zip(fast, gen)):
         assert f.shape == g.shape
-        assert np.array_equal(np.isnan(f.real), np.isnan(g.real)) and np.isnan(f[0]).all() and not np.isnan(f[1]).any()
+        assert np.array_equal(np.isnan(f.real), np.isnan(g.real))
+        if i < 3:
+            assert np.isnan(f[0]).all() and not np.isnan(f[1]).any()
+        else:
+            assert not np.isnan(f.real).any()                              # the far field is defined everywhere
         ok = ~np.isnan(g.real)
-        assert np.max(np.abs(f[ok] - g[ok])) < 1e-12 * np.max(np.abs(g[ok]))
+        assert np.max(np.abs(f[ok] - g[ok])) < 1e-12 * np.max(np.abs(g[ok])), i
 
 
 @pytest.mark.parametrize("force_lu_fallback", [False, True])
