@@ -152,7 +152,7 @@ constexpr int PW = 8;
 
 // symmetric path: smallest accepted |diagonal| / |entry of its row|: every multiplier <= 10 (partial pivoting: <= 1).  It is the growth
 // check (GROWTH_MAX) that bounds the error; with it in place the limit of 2 of round 1 only sent close-sphere systems at low k
-// to the pivoted LU that the symmetric path solves to the same 1e-13 (profiles/r02_ldlt_fallback_survey.txt: 40 % -> 10 % of them)
+// to the pivoted LU that the symmetric path solves to the same 1e-13 (profiles/r02_ldlt_fallback_survey.txt: a third -> a ninth of them)
 constexpr double NOPIV_REL = 0.1;
 constexpr int STRIP_CACHE_ROWS = 1024;   // rows of the strip kept in LDS (one per thread): 1024 x 8 x 16 B = 128 KiB
 
