@@ -96,7 +96,7 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
                            bool symmetric = false, bool amax_ready = false);
 // complex-symmetric A = U^T U in row form on the upper triangle (kernels_lu.hip), fused with the solve of the augmented columns
 bool sym_small_path(int n_active, int nrhs);      // whether launch_sym_factor_solve takes its one-launch LDS-resident path
-// (n_active: rows n_active .. n_pad-1 are identity padding; systems of at most 96 active rows run in one LDS-resident launch)
+// (n_active: rows n_active .. n_pad-1 are identity padding; systems of at most 128 active rows run in one LDS-resident launch)
 int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_info, void* d_work,
                             size_t work_bytes, hipStream_t st, bool amax_ready = false, int n_active = 0);
 // where the symmetric factorisation keeps max |A|, max |U| per system inside its workspace (unsigned 64-bit patterns of doubles)

@@ -1687,9 +1687,9 @@ __global__ void __launch_bounds__(256) k_rhs_compact(cplx* __restrict__ A, long 
 // forward elimination, checks and back substitution - the blocked path above spends its time in per-panel launches there
 // (4096 systems of N = 72: 5.2 of 6.8 ms in diagonal-block kernels that run one 64 x 64 block per workgroup).
 // Same factorisation A = U^T U on the upper triangle (rows n .. of an identity-padded system are skipped), same acceptance tests
-// and info codes; U is written back to the upper triangle.  n <= 96 rows and nrhs <= 8 (n (n + nrhs + 1) complex of LDS).
+// and info codes; U is written back to the upper triangle.  n <= 128 rows, nrhs <= 8 and n + nrhs <= 128 (two 64-column lane slots; packed upper triangle of LDS).
 // ---------------------------------------------------------------------------------------------
-constexpr int SMALL_N_MAX = 96;
+constexpr int SMALL_N_MAX = 128;           // and n + nrhs <= 128 (two 64-column lane slots), packed store within the LDS
 constexpr int SMALL_RHS_MAX = 8;
 constexpr int SMALL_THREADS = 512;
 // LDS of k_small_utu: packed upper triangle with the right-hand sides appended to each row, then 1/a_cc and 1/sqrt(a_cc) per row
@@ -1699,7 +1699,7 @@ static inline size_t small_utu_lds(int n, int nrhs) { return ((size_t)n * (n + 1
 // (TWO); a finished row (row c + 1 after step c) is published once to the packed LDS store, which the other waves read it from
 // and which the back substitution and the write-back then use.  One barrier per step, no read-modify-write through LDS.
 template <int KR, bool TWO>
-__global__ void __launch_bounds__(SMALL_THREADS, 4) k_small_utu(cplx* __restrict__ A, long long lda, long long sys_stride, int n, int n_pad, int nrhs,
+__global__ void __launch_bounds__(SMALL_THREADS, (KR <= 9 ? 4 : 2)) k_small_utu(cplx* __restrict__ A, long long lda, long long sys_stride, int n, int n_pad, int nrhs,
                                                               int* __restrict__ info, unsigned long long* __restrict__ growth, double rel, int amax_ready) {
   // row r of the packed store: columns r .. n-1 of the matrix, then the nrhs right-hand sides; element (r, c) at off(r) + c, nc = n + nrhs
   extern __shared__ cplx sa[];
@@ -1884,7 +1884,10 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_diag_utu_reg(cplx* __restrict
   if (tid == 0 && bad && info[s] == 0) info[s] = -(j + 1);
 }
 
-bool sym_small_path(int n_active, int nrhs) { return n_active > 0 && n_active <= SMALL_N_MAX && nrhs <= SMALL_RHS_MAX && !getenv("BIEM_NO_SMALL_PATH"); }
+bool sym_small_path(int n_active, int nrhs) {
+  return n_active > 0 && n_active <= SMALL_N_MAX && nrhs <= SMALL_RHS_MAX && n_active + nrhs <= 128 && small_utu_lds(n_active, nrhs) <= 160 * 1024 - 2048 &&
+         !getenv("BIEM_NO_SMALL_PATH");
+}
 
 int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long lda, long long sys_stride, int* d_info, void* d_work,
                             size_t work_bytes, hipStream_t st, bool amax_ready, int n_active) {
@@ -1919,7 +1922,8 @@ int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long 
     if (!two) { if (kr <= 4) BIEM_SMALL(4, false) else BIEM_SMALL(8, false) }
     else if (kr <= 8) BIEM_SMALL(8, true)
     else if (kr <= 9) BIEM_SMALL(9, true)
-    else BIEM_SMALL(12, true)
+    else if (kr <= 12) BIEM_SMALL(12, true)
+    else BIEM_SMALL(16, true)
 #undef BIEM_SMALL
     hipLaunchKernelGGL(k_growth_check, dim3((nb + 63) / 64), dim3(64), 0, st, nb, n_pad, growth, d_info, growth_max);
     BIEM_LAUNCHCHK();

@@ -497,11 +497,12 @@ def test_many_small_systems_are_chunked(amd):
         assert abs(u[i] - O.uscat(res, np.zeros((1, 3)))[0]) < 1e-11 * abs(u[i]), i
 
 
-@pytest.mark.parametrize("bt,d,n_end,B", [("ba", 3, 6, 2), ("ba", 3, 4, 5), ("a", 2, 9, 5), ("ba", 3, 3, 9)])
+@pytest.mark.parametrize("bt,d,n_end,B", [("ba", 3, 6, 2), ("ba", 3, 4, 5), ("a", 2, 9, 5), ("ba", 3, 3, 9), ("ba", 3, 6, 3), ("ba", 3, 5, 5), ("a", 2, 13, 5)])
 def test_small_systems_one_launch_path(amd, bt, d, n_end, B, monkeypatch):
-    """Systems of at most 96 unknowns are factorised and solved in ONE launch with the whole system in LDS (k_small_utu), larger
-    ones by the blocked row form: both on the same inputs (BIEM_NO_SMALL_PATH=1 forces the blocked one) and against the oracle.
-    N = 72 (cfg 1), 80, 85 and 81 - one to three 64-row panels of the blocked path, every register layout of the small one."""
+    """Systems of at most 128 unknowns (N + nrhs <= 128) are factorised and solved in ONE launch with the whole system in LDS
+    (k_small_utu), larger ones by the blocked row form: both on the same inputs (BIEM_NO_SMALL_PATH=1 forces the blocked one) and
+    against the oracle.  N = 72 (cfg 1), 80, 85, 81, 108, 125 (2 right-hand sides would no longer fit: 1 here) and 125 in 2-D -
+    one to two 64-row panels of the blocked path, every register layout of the small one."""
     c = amd.create_from_branching_types(bt)
     rng = np.random.default_rng(B * 7 + n_end)
     cen = np.zeros((B, d)); cen[:, 0] = 2.6 * np.arange(B); cen[:, 1:] = 0.3 * rng.normal(size=(B, d - 1))
@@ -1095,7 +1096,7 @@ def test_sym_factor_rejections_and_growth(lib, monkeypatch):
     B[1, 20, 150] = np.nan
     bad = run(B)
     assert bad[0] == 0 and bad[1] < 0
-    # the same acceptance tests in the one-launch path of small systems (at most 96 active rows, the whole system in LDS)
+    # the same acceptance tests in the one-launch path of small systems (at most 128 active rows, the whole system in LDS)
     N = 64
     A = np.zeros((4, N, N + 8), dtype=np.complex128)
     A[:, :, :N] = np.eye(N)
