@@ -608,7 +608,7 @@ def biem(
     Solver: the reference passes every system to a general dense solve (``_biem.py:797``).  Here the system is first brought
     to its complex-symmetric form (real harmonics, symmetric scaling) and factored as U^T U (Cholesky-type, no conjugation)
     without interchanges - half the flops; a system in which a multiplier would exceed 10, or whose factor grew by more than
-    1e3, is solved by the pivoted LU instead (``BIEM_SOLVER=lu`` in the environment: pivoted LU for all).  Both give the
+    200, is solved by the pivoted LU instead (``BIEM_SOLVER=lu`` in the environment: pivoted LU for all).  Both give the
     reference's ``density`` to rounding.
     """
     if translational_coefficients_method not in (None, "gumerov", "plane_wave", "triplet"):

@@ -45,7 +45,7 @@ size_t lu_workspace_bytes(int nb, int n_pad, int nrhs) {
 // 64-bit atomicMax keeps the maximum and a NaN sticks.  k_growth_check marks a system (info = -(n_pad + 1)) whose factor U grew
 // by more than GROWTH_MAX over A, or holds a non-finite entry; the caller re-solves it with the pivoted LU.
 // ---------------------------------------------------------------------------------------------
-constexpr double GROWTH_MAX = 1.0e3;
+constexpr double GROWTH_MAX = 2.0e2;     // (1e3 with multipliers <= 2 in round 1; with multipliers <= 10 the product of the two limits is kept)
 __device__ inline double cabs1(cplx v) { return fabs(v.x) + fabs(v.y); }
 __device__ inline double nan_max(double a, double b) { return !(b <= a) ? b : a; }       // NaN in b wins; NaN in a stays
 __device__ inline void block_max_publish(double m, unsigned long long* dst) {              // 1-D blocks of whole waves
