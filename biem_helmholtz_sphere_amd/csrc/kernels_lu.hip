@@ -1980,8 +1980,13 @@ int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long 
     ProfScope ps(PK_BACK, st, 4.0 * (double)nb * n_pad * (double)n_pad * nrhs);
     const double inv_rel2 = 1.0 / (nopiv * nopiv);
     cplx* Y = (cplx*)d_work;         // the panel region of the workspace is free in the row form: room for 4 * 64 right-hand sides per system
-    if (nrhs > 4 * NB) {
-      // more right-hand sides than the compact copy holds: the column-block form on the augmented columns (same checks)
+    const char* bf = getenv("BIEM_BACK_FORM");
+    // Few systems: the row form has one workgroup per system and 64-row block (a quarter of the CUs busy at 64 systems); the
+    // column-block form spreads a system's rows over workgroups (cfg 4, N = 4064: 64 systems 6.1 -> 5.1 ms, 8 systems 5.7 -> 2.6 ms,
+    // one system per call 22.8 -> 20.6 ms; at 256+ systems the row form wins: it reads U once in long runs).  BIEM_BACK_FORM=row|col forces one.
+    const bool col_form = bf ? bf[0] == 'c' : nb <= 64;
+    if (nrhs > 4 * NB || (col_form && nrhs > 0)) {
+      // (also: more right-hand sides than the compact copy of the row form holds) the column-block form on the augmented columns, same checks
       for (int jr = n_pad - BS; jr >= 0; jr -= BS) {
         hipLaunchKernelGGL(k_back_diag, dim3(nb, nrhs), dim3(64), 0, st, A, lda, sys_stride, A + n_pad, lda, sys_stride, jr);
         if (jr > 0)
