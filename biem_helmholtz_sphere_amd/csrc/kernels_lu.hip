@@ -401,6 +401,7 @@ struct TileGrid {
   cplx* pout; long long pout_ld, pout_stride; int pcol_tx;
   int tri;                                      // 1: only tiles with tx <= ty (square region, symmetric update); 2: only tx >= ty
   const int* tri_map; int tri_full;             // (ty << 16 | tx) of the first tri_full tiles of that order (the full bands)
+  int blk_sh;                                   // log2 of the tiles per XCD block of the workgroup -> tile map: 6, or 3 for small launches
   unsigned long long per_sys_magic;             // ceil(2^40 / per_sys): t / per_sys = (t * magic) >> 40 for t < 2^25 (scalar multiply, no VALU division)
 };
 
@@ -538,9 +539,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm3m_pipe(cplx* __restrict__ A, lo
   auto next_tile = [&]() -> int {
     for (;;) {
       q += nblk;
-      int base = 64 * ((q >> 6) * 8 + xl);
+      int base = ((q >> tg.blk_sh) * 8 + xl) << tg.blk_sh;
       if (base >= tg.ntiles) return -1;
-      int t = base + (q & 63);
+      int t = base + (q & ((1 << tg.blk_sh) - 1));
       if (t < tg.ntiles) return t;
     }
   };
@@ -1000,6 +1001,11 @@ static int launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, lo
   tg.ty_n = (rrows + BM3 - 1) / BM3; tg.tx_n = (rcols + BN3 - 1) / BN3;
   tg.per_sys = tri ? tg.ty_n * (tg.ty_n + 1) / 2 : tg.ty_n * tg.tx_n; tg.full_bands = tg.ty_n / 8; tg.ntiles = tg.per_sys * nb;
   tg.tri_map = tri_map; tg.tri_full = 32 * tg.full_bands * tg.full_bands + 4 * tg.full_bands;
+  // Workgroups with the same blockIdx % 8 (one XCD) sweep blocks of 64 consecutive tiles together (shared operand panels in that
+  // XCD's L2).  A small launch - one system, or the last groups of a factorisation - would leave most workgroups without a
+  // tile that way (63 tiles: all in block 0, i.e. on the 8 workgroups of one label, 8 tiles each in sequence: 204 us for a
+  // K = 192 tile row of one N = 4064 system): blocks of 8 tiles then.
+  tg.blk_sh = tg.ntiles < 2048 ? 3 : 6;
   tg.per_sys_magic = ((1ULL << 40) + (unsigned long long)tg.per_sys - 1) / (unsigned long long)tg.per_sys;
   if (tg.ntiles >= (1 << 25)) { set_error("biem_lu: more than 2^25 tiles in one update launch"); return BIEM_ERR_ARG; }   // unreachable: 2^25 tiles are 2 TB of matrix
   tg.row_begin = row_begin; tg.row_end = row_end; tg.col_begin = col_begin; tg.col_end = col_end; tg.brow = brow;
