@@ -1724,7 +1724,8 @@ __global__ void __launch_bounds__(SMALL_THREADS, (KR <= 9 ? 4 : 2)) k_small_utu(
   extern __shared__ cplx sa[];
   __shared__ int bad_row;
   constexpr int NW = SMALL_THREADS / 64;
-  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nc = n + nrhs;
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nc = n + nrhs;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: the row tests below become scalar branches
   auto off = [&](int r) { return r * nc - (r * (r - 1)) / 2 - r; };
   cplx* ipiv = sa + (size_t)n * (n + 1) / 2 + (size_t)n * nrhs;            // 1 / a_cc
   cplx* isq = ipiv + n;                                                     // 1 / sqrt(a_cc)
@@ -1843,7 +1844,8 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_diag_utu_reg(cplx* __restrict
   cplx* isq = lrow + 2 * NB;                       // 1 / sqrt(d_r)
   auto uoff = [](int r) { return r * NB - (r * (r - 1)) / 2 - r; };
   auto yoff = [](int i) { return (i * (i + 1)) / 2; };
-  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: the row tests below become scalar branches
   cplx* Ab = A + (size_t)s * sys_stride + (size_t)j * lda + j;
   if (tid == 0) bad = 0;
   cplx a0[KR], y1[KR];
