@@ -291,8 +291,11 @@ static int solve_impl(const biem_plan* plan, int nb, int B, int nrhs, const doub
     // right-hand side into column n_pad of the augmented matrix (padded rows: zero via fill_pad? -> set explicitly below)
     // small systems are solved in one LDS-resident launch that never reads the padding rows / columns: they are not written then
     const bool small = symmetric && sym_small_path(L.N, nrhs);
+    // blocks of ball pairs with the same displacement and the same (radius, alpha, beta) on either side are contracted once
+    const FillDedupe dd = {d_radii, d_alpha, d_beta};
     if (symmetric)
-      rc = launch_fill_sym(plan, c, B, ks, cen, geom_batched, tb, A, L.lda, L.sys_stride, L.n_pad, T, fill_workspace_bytes(plan, c, B), st, small);
+      rc = launch_fill_sym(plan, c, B, ks, cen, geom_batched, tb, A, L.lda, L.sys_stride, L.n_pad, T, fill_workspace_bytes(plan, c, B), st, small,
+                           (!geom_batched && !ab_batched) ? &dd : nullptr);
     else
       rc = launch_fill(plan, c, B, ks, cen, geom_batched, tb, BIEM_FILL_EQUILIBRATED, A, L.lda, L.sys_stride, L.n_pad, T,
                        fill_workspace_bytes(plan, c, B), st);

@@ -83,8 +83,14 @@ int launch_density(const biem_plan* p, int nb, int B, int nrhs, const double* d_
                    long long rhs_stride, const double* d_tab, double* d_density, hipStream_t st, bool slot_order = false);
 // the complex-symmetric form A~ = R W^H M W R^-1 in the plan's internal slot order, written only where the L D L^T factorisation
 // reads it (lower triangle + diagonal 64 x 64 tiles); fill_sym_bytes = those bytes per system
+// FillDedupe (optional): per-ball radii [B], alpha [B], beta [B] (complex) shared by all systems of the call.  Ball pairs with the
+// same displacement vector and the same (radius, alpha, beta) on either side have IDENTICAL blocks of A~ (translation invariance of
+// (S|R)): the block is contracted once and stored to every such pair (lattices of equal spheres: cfg 3 has 24 distinct blocks
+// among its 120 pairs).  nullptr: every pair on its own (batched geometry or per-system alpha / beta).
+struct FillDedupe { const double* radii; const double* alpha; const double* beta; };
 int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const double* d_centers, int geom_batched, const double* d_tab,
-                    double* d_A, long long lda, long long sys_stride, int n_pad, void* d_work, size_t work_bytes, hipStream_t st, bool no_padding = false);
+                    double* d_A, long long lda, long long sys_stride, int n_pad, void* d_work, size_t work_bytes, hipStream_t st, bool no_padding = false,
+                    const FillDedupe* dedupe = nullptr);
 double fill_sym_bytes(int n_pad);
 int launch_uscat(const biem_plan* p, int nb, int B, int P, const double* d_k, const double* d_eta, const double* d_centers,
                  const double* d_radii, int geom_batched, const double* d_density, const double* d_points, int flags,

@@ -342,6 +342,10 @@ static bool fill_sym_entry_fits(const biem_plan* p, size_t* shm_out) {
   return p->pair_lists_ok && (int)p->qchunk.size() > 1 && shm <= 160 * 1024 && p->H2lin <= 8 * 1024;
 }
 
+// pair classes of the symmetric fill (k_pair_dedupe), behind the pair tables: nrep (+3 pad), rep_list[np], dup_ptr[np + 1], dup_bb[np]
+static size_t fill_dedupe_bytes(int B) { const size_t np = (size_t)B * (B - 1) / 2; return ((3 * np + 5) * sizeof(int) + 15) / 16 * 16; }
+constexpr int kDedupeMaxPairs = 2048;       // (the class search is quadratic in the pairs, in one workgroup)
+
 size_t fill_workspace_bytes(const biem_plan* p, int nb, int B) {
   // pair tables of the general / entry forms: [nb][B][B][H2 or H2lin]; of the systems-in-lanes form (needed where the entry form
   // does not fit, or when BIEM_FILL_FORM=sys forces it): [nb rounded up to 64][pairs][H2] + q factors
@@ -349,7 +353,7 @@ size_t fill_workspace_bytes(const biem_plan* p, int nb, int B) {
   const size_t b = ((size_t)(B * (B - 1) / 2) * p->H2 + (size_t)B * p->n_end) * nbp;
   const char* form = getenv("BIEM_FILL_FORM");
   const bool need_sys = (form && form[0] == 's') || !fill_sym_entry_fits(p, nullptr);
-  return (need_sys && b > a ? b : a) * sizeof(cplx);
+  return (need_sys && b > a ? b : a) * sizeof(cplx) + fill_dedupe_bytes(B);
 }
 
 int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const double* d_centers, int geom_batched,
@@ -400,6 +404,75 @@ int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const doub
 // registers during the previous combination's contraction - so the term lists are read from L2 once per workgroup.
 // Each thread runs the four independent chains of its 2 x 2 block (the per-term chain idx -> T -> fma is LDS-latency bound).
 // ---------------------------------------------------------------------------------------------
+// Pair classes (FillDedupe, common.hpp).  Upper pairs are numbered pr = bp (bp - 1) / 2 + b, b < bp.  out: [0] = number of classes,
+// [4 ..] rep_list[class] = its first pair, then dup_ptr[class .. class + 1] into dup_bb[] = (b << 16 | bp) of the class's pairs
+// (the representative first).  enable = 0: every pair its own class.  One workgroup; quadratic search, npairs <= kDedupeMaxPairs.
+__global__ void __launch_bounds__(256) k_pair_dedupe(int B, int d, int npairs, const double* __restrict__ centers, const double* __restrict__ radii,
+                                                      const double* __restrict__ alpha, const double* __restrict__ beta, int enable,
+                                                      int* __restrict__ out) {
+  extern __shared__ int sd_int[];
+  int* cls = sd_int;                 // [B] first ball with the same (radius, alpha, beta)
+  int* rep = cls + B;                // [npairs] first pair of the same class
+  int* cnt = rep + npairs;           // [npairs] members per representative, then write cursors
+  int* rep_list = out + 4;
+  int* dup_ptr = rep_list + npairs;
+  int* dup_bb = dup_ptr + npairs + 1;
+  const int tid = threadIdx.x;
+  auto pair_of = [&](int pr, int& b, int& bp) {
+    int bb = (int)((sqrtf(8.0f * (float)pr + 1.0f) + 1.0f) * 0.5f);
+    while (bb * (bb - 1) / 2 > pr) --bb;
+    while ((bb + 1) * bb / 2 <= pr) ++bb;
+    bp = bb; b = pr - bb * (bb - 1) / 2;
+  };
+  if (!enable) {
+    for (int p = tid; p < npairs; p += 256) { int b, bp; pair_of(p, b, bp); rep_list[p] = p; dup_ptr[p] = p; dup_bb[p] = b << 16 | bp; }
+    if (tid == 0) { out[0] = npairs; dup_ptr[npairs] = npairs; }
+    return;
+  }
+  for (int b = tid; b < B; b += 256) {
+    int c = b;
+    for (int b2 = 0; b2 < b; ++b2)
+      if (radii[b2] == radii[b] && alpha[2 * b2] == alpha[2 * b] && alpha[2 * b2 + 1] == alpha[2 * b + 1] && beta[2 * b2] == beta[2 * b] &&
+          beta[2 * b2 + 1] == beta[2 * b + 1]) { c = b2; break; }
+    cls[b] = c;
+  }
+  __syncthreads();
+  // per pair: its ball classes (packed) and its displacement, once - the quadratic search below then only compares
+  int* key = cnt + npairs;                                   // [npairs] cls[b] << 16 | cls[bp]
+  double* disp = (double*)(key + npairs + ((B + 3 * npairs) & 1));    // [npairs][d], 8-byte aligned
+  for (int p = tid; p < npairs; p += 256) {
+    int b, bp; pair_of(p, b, bp);
+    key[p] = cls[b] << 16 | cls[bp];
+    for (int i = 0; i < d; ++i) disp[p * d + i] = centers[bp * d + i] - centers[b * d + i];
+  }
+  __syncthreads();
+  for (int p = tid; p < npairs; p += 256) {
+    int r = p;
+    const int kp = key[p];
+    for (int q = 0; q < p; ++q) {
+      if (key[q] != kp) continue;
+      bool same = true;
+      for (int i = 0; i < d; ++i) same = same && (disp[q * d + i] == disp[p * d + i]);
+      if (same) { r = q; break; }
+    }
+    rep[p] = r; cnt[p] = 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int p = 0; p < npairs; ++p) cnt[rep[p]]++;
+    int nrep = 0, pos = 0;
+    for (int p = 0; p < npairs; ++p)
+      if (rep[p] == p) { rep_list[nrep] = p; dup_ptr[nrep] = pos; pos += cnt[p]; cnt[p] = dup_ptr[nrep]; rep[p] = -nrep - 1; ++nrep; }   // rep[p] < 0: class index
+    dup_ptr[nrep] = pos;
+    out[0] = nrep;
+    for (int p = 0; p < npairs; ++p) {           // pairs in ascending order: the representative is the first of its class
+      const int r = rep[p] < 0 ? p : rep[p];
+      int b, bp; pair_of(p, b, bp);
+      dup_bb[cnt[r]++] = b << 16 | bp;
+    }
+  }
+}
+
 constexpr int FILL_SYM_THREADS = 1024;
 constexpr int FILL_SYM_MAXT = 8;           // pair-table elements prefetched per thread: H2lin <= 8 * 1024
 
@@ -412,7 +485,8 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_sym(int H, int U, int
                                                                 int terms_max, int pairs_max, const uint32_t* __restrict__ qptr,
                                                                 const double* __restrict__ qcoef, const uint16_t* __restrict__ qidx,
                                                                 const cplx* __restrict__ T, const cplx* __restrict__ tab,
-                                                                cplx* __restrict__ A, long long lda, long long sys_stride) {
+                                                                cplx* __restrict__ A, long long lda, long long sys_stride,
+                                                                const int* __restrict__ classes) {
   extern __shared__ char smem[];
   cplx* sT = (cplx*)smem;                                  // [H2] pair table of the current combination
   cplx* sQ = sT + H2;                                      // [2][n_end]: q of the row ball, q of the column ball
@@ -434,7 +508,13 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_sym(int H, int U, int
   const int row_c = u, row_s = r2 ? U + spos[u] : 0, col_c = v, col_s = c2 ? U + spos[v] : 0;
   const int nrow = deg[rh], ncol = deg[ch];
   const double q2 = 0.70710678118654752440;
-  const int ncomb = npairs * nb;
+  // pair classes (k_pair_dedupe): a combination is (system, class); its block is contracted once from the representative pair's
+  // table and stored to every pair of the class
+  const int nrep = classes[0];
+  const int* rep_list = classes + 4;
+  const int* dup_ptr = rep_list + npairs;
+  const int* dup_bb = dup_ptr + npairs + 1;
+  const int ncomb = nrep * nb;
   // eight named registers instead of an array: hipcc kept every array form (plain, unrolled, compile-time indexed through
   // lambdas) in scratch memory
 #define BIEM_TN_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
@@ -449,14 +529,14 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_sym(int H, int U, int
     bp = bb; b = pr - bb * (bb - 1) / 2;
   };
   auto table_of = [&](int cb) -> const cplx* {
-    const int s = cb / npairs, pr = cb - s * npairs;
+    const int s = cb / nrep, pr = rep_list[cb - s * nrep];
     int b, bp; pair_of(pr, b, bp);
     return T + ((size_t)s * B * B + (size_t)b * B + bp) * H2;
   };
   int comb = blockIdx.y;
   if (comb < ncomb) { const cplx* Tp_ = table_of(comb); BIEM_TN_LIST(BIEM_TN_LOAD) }
   for (; comb < ncomb; comb += gridDim.y) {
-    const int s = comb / npairs, pr = comb - s * npairs;
+    const int s = comb / nrep, ci = comb - s * nrep, pr = rep_list[ci];
     int b, bp; pair_of(pr, b, bp);
     __syncthreads();                                       // the previous combination's readers are done (also orders the chunk loads)
     BIEM_TN_LIST(BIEM_TN_PUT)
@@ -505,11 +585,15 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_sym(int H, int U, int
     }
     const cplx scale = cmul(sQ[nrow], sQ[n_end + ncol]);
     cplx* As = A + (size_t)s * sys_stride;
+    const int e0 = dup_ptr[ci], e1 = dup_ptr[ci + 1];
     auto put = [&](int rslot, int cslot, cplx val) {
-      const int row = b * H + rslot, col = bp * H + cslot;   // b < bp: strictly above the diagonal
       const cplx w = cmul(val, scale);
-      As[(size_t)row * lda + col] = w;
-      if ((row >> 6) == (col >> 6)) As[(size_t)col * lda + row] = w;     // a diagonal 64 x 64 tile is read whole: mirror (A~ = A~^T)
+      for (int e = e0; e < e1; ++e) {                        // every pair of the class (the representative first)
+        const int bb = dup_bb[e];
+        const int row = (bb >> 16) * H + rslot, col = (bb & 0xffff) * H + cslot;   // b < bp: strictly above the diagonal
+        As[(size_t)row * lda + col] = w;
+        if ((row >> 6) == (col >> 6)) As[(size_t)col * lda + row] = w;   // a diagonal 64 x 64 tile is read whole: mirror (A~ = A~^T)
+      }
     };
     put(row_c, col_c, x00);
     if (c2) put(row_c, col_s, x01);
@@ -664,7 +748,8 @@ double fill_sym_bytes(int n_pad) {
 }
 
 int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const double* d_centers, int geom_batched, const double* d_tab,
-                    double* d_A, long long lda, long long sys_stride, int n_pad, void* d_work, size_t work_bytes, hipStream_t st, bool no_padding) {
+                    double* d_A, long long lda, long long sys_stride, int n_pad, void* d_work, size_t work_bytes, hipStream_t st, bool no_padding,
+                    const FillDedupe* dedupe) {
   const int H = p->H, N = B * H, U = (int)(p->units.size() / 2);
   if (nb <= 0 || B <= 0) return BIEM_OK;
   if (lda < n_pad || n_pad < N || n_pad % 64) { set_error("biem_fill (symmetric): lda / n_pad too small or n_pad not a multiple of 64"); return BIEM_ERR_ARG; }
@@ -717,6 +802,15 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
     BIEM_LAUNCHCHK();
     const int npairs = B * (B - 1) / 2;
     const long long ncomb = (long long)npairs * nb;
+    int* classes = (int*)((char*)d_work + fill_workspace_bytes(p, nb, B) - fill_dedupe_bytes(B));
+    {
+      const bool on = dedupe && !geom_batched && npairs <= kDedupeMaxPairs && B <= 65535 && !getenv("BIEM_FILL_NO_DEDUPE");
+      const size_t shm_dd = on ? (size_t)(B + 3 * npairs + 2) * sizeof(int) + (size_t)npairs * p->d * sizeof(double) : 0;
+      if (shm_dd > 48 * 1024) BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_pair_dedupe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_dd));
+      hipLaunchKernelGGL(k_pair_dedupe, dim3(1), dim3(256), shm_dd, st, B, p->d, npairs, d_centers,
+                         on ? dedupe->radii : nullptr, on ? dedupe->alpha : nullptr, on ? dedupe->beta : nullptr, on ? 1 : 0, classes);
+      BIEM_LAUNCHCHK();
+    }
     // enough workgroups to fill the chip a few times over, each with a long loop over combinations
     long long gy = (8 * 256 + nchunks - 1) / nchunks;
     if (gy < 1) gy = 1;
@@ -728,7 +822,7 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
     BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_fill_sym<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                  \
     hipLaunchKernelGGL(k_fill_sym<KT>, dim3(nchunks, (unsigned)gy), dim3(FILL_SYM_THREADS), shm, st, H, U, p->H2lin, p->n_end, B, nb, npairs, \
                        p->d_deg, p->d_units, p->d_spos, p->d_qchunk, p->qchunk_terms_max, p->qchunk_pairs_max, p->d_q2ptr, p->d_q2coef,   \
-                       p->d_q2idx16, T, (const cplx*)d_tab, (cplx*)d_A, lda, sys_stride);                                                 \
+                       p->d_q2idx16, T, (const cplx*)d_tab, (cplx*)d_A, lda, sys_stride, classes);                                        \
   }
     if (kt_need <= 1) BIEM_LAUNCH_FILL_SYM(1)
     else if (kt_need <= 2) BIEM_LAUNCH_FILL_SYM(2)

@@ -566,6 +566,43 @@ def test_uscat_point_per_lane_matches_generic(amd, bt, d, n_end, B, monkeypatch)
         assert np.max(np.abs(f[ok] - g[ok])) < 1e-12 * np.max(np.abs(g[ok])), i
 
 
+def test_symmetric_fill_pair_classes(amd, monkeypatch):
+    """Ball pairs with the same displacement vector and the same (radius, alpha, beta) on either side share their block of the
+    symmetric matrix: it is contracted once and stored to every pair of the class (k_pair_dedupe).  A 3 x 2 lattice where the classes
+    are cut three ways - all balls alike; two radii; two Robin coefficients - each against the oracle, and bit for bit against the
+    same call with BIEM_FILL_NO_DEDUPE=1 (the copies are copies)."""
+    c = amd.create_from_branching_types("ba")
+    gx, gy = np.meshgrid(np.arange(3) * 3.0, np.arange(2) * 3.0, indexing="ij")
+    cen = np.stack([gx.ravel(), gy.ravel(), np.zeros(6)], -1)
+    ks = np.array([0.8, 2.1])
+    dirs = np.zeros((3, 2)); dirs[0] = 1.0; dirs[2] = 0.3
+    x = np.array([[10.0, 1.0, 2.0], [-4.0, 5.0, -1.0], [3.0, -6.0, 0.5]])
+    cases = [
+        (np.ones(6), 1.0, 0.4),
+        (np.array([1.0, 0.7, 1.0, 0.7, 1.0, 1.0]), 1.0, 0.4),
+        (np.ones(6), np.array([[1.0, 1.0, 2.0 + 0.5j, 1.0, 2.0 + 0.5j, 1.0]]), np.array([[0.4, 0.4, 0.4, 0.1, 0.4, 0.4]])),
+    ]
+    for rad, alpha, beta in cases:
+        out = []
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("BIEM_FILL_NO_DEDUPE", "1")
+            else:
+                monkeypatch.delenv("BIEM_FILL_NO_DEDUPE", raising=False)
+            uin, ugr = amd.plane_wave(k=_dev(ks), direction=_dev(dirs))
+            a = alpha if np.isscalar(alpha) else _dev(alpha, torch.complex128)
+            b = beta if np.isscalar(beta) else _dev(beta, torch.complex128)
+            calc = amd.biem(c, centers=_dev(cen)[None], radii=_dev(rad)[None], k=_dev(ks), n_end=7, alpha=a, beta=b, uin=uin, uin_grad=ugr)
+            out.append((calc.density.cpu().numpy(), calc.uscat(_dev(x.T)).cpu().numpy()))
+        assert np.array_equal(out[0][0], out[1][0])
+        for i, k in enumerate(ks):
+            uo, go = O.plane_wave(k, dirs[:, i])
+            res = O.solve_biem("ba", centers=cen, radii=rad, k=k, n_end=7, alpha=np.ravel(alpha) if not np.isscalar(alpha) else alpha,
+                               beta=np.ravel(beta) if not np.isscalar(beta) else beta, uin=uo, uin_grad=go)
+            ref = O.uscat(res, x)
+            assert np.max(np.abs(out[0][1][:, i] - ref)) < 1e-10 * np.max(np.abs(ref))
+
+
 @pytest.mark.parametrize("force_lu_fallback", [False, True])
 def test_batched_geometry_and_points_per_system(amd, force_lu_fallback, monkeypatch):
     """(force_lu_fallback: every system is rejected by the symmetric path and re-solved by the pivoted LU from gathered
