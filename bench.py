@@ -381,6 +381,9 @@ def main() -> int:
     fj = profile_json("r02_fill_traffic.json")
     fill_traffic = fj["bytes_per_system"] * nloc if fj and cfg == 3 else None
 
+    cen_ = np.asarray(w["centers"], dtype=np.float64)
+    disp_ = [tuple((cen_[bp] - cen_[b]).tolist()) for bp in range(len(cen_)) for b in range(bp)]
+    pair_classes = {"pairs": len(disp_), "classes": len(set(disp_)) if solver == "ldlt" and not os.environ.get("BIEM_FILL_NO_DEDUPE") else len(disp_)}
     issued = 0.75 * alg_tflops if alg_tflops else None     # 3M: 3 real products per complex multiply-add = 6 of the 8 flops
     # what a pure stream of the same MFMA instruction sustains on THIS box (0.3 s, after the timed region): context for `frac`,
     # which stays priced against the nominal 78.6 TFLOP/s
@@ -418,7 +421,9 @@ def main() -> int:
             "avg_launch_ms": ms[gi] / launches[gi] if launches[gi] else None, "launches": launches[gi],
             "share_of_step": ms[gi] / (dt * 1e3) if dt > 0 else None,
         },
-        "fill": {"bound": "hbm", "achieved": fill_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fill_gbs / HBM_PEAK_GBS if fill_gbs else None,
+        # (pair classes: ball pairs with the same displacement and the same sphere on either side share their block of the matrix,
+        # contracted once and stored to every pair of the class - all radii and Robin coefficients are equal in these workloads)
+        "fill": {"bound": "hbm", "pair_classes": pair_classes, "achieved": fill_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fill_gbs / HBM_PEAK_GBS if fill_gbs else None,
                  "bytes_counted": "what the factorisation reads: upper triangle + diagonal 64 x 64 tiles of the symmetric form (default path), or 16 N^2 per system (BIEM_SOLVER=lu)",
                  "traffic": fill_traffic, "traffic_source": "profiles/r02_fill_traffic.json (rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE), scaled" if fill_traffic else None},
         "stage_ms_per_step": {n: m / args.steps for n, m in zip(CLASSES, ms)},
