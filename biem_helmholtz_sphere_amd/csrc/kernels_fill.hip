@@ -804,7 +804,10 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
     const long long ncomb = (long long)npairs * nb;
     int* classes = (int*)((char*)d_work + fill_workspace_bytes(p, nb, B) - fill_dedupe_bytes(B));
     {
-      const bool on = dedupe && !geom_batched && npairs <= kDedupeMaxPairs && B <= 65535 && !getenv("BIEM_FILL_NO_DEDUPE");
+      // (a handful of systems: fewer, longer combinations would leave most of the chip without a workgroup - one N = 4064 system
+      // filled in 0.49 instead of 0.17 ms with classes - so every pair stays on its own below 8 systems)
+      const char* mn = getenv("BIEM_FILL_DEDUPE_MIN");                       // (tests: classes for small batches too)
+      const bool on = dedupe && !geom_batched && nb >= (mn ? atoi(mn) : 8) && npairs <= kDedupeMaxPairs && B <= 65535 && !getenv("BIEM_FILL_NO_DEDUPE");
       const size_t shm_dd = on ? (size_t)(B + 3 * npairs + 2) * sizeof(int) + (size_t)npairs * p->d * sizeof(double) : 0;
       if (shm_dd > 48 * 1024) BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_pair_dedupe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_dd));
       hipLaunchKernelGGL(k_pair_dedupe, dim3(1), dim3(256), shm_dd, st, B, p->d, npairs, d_centers,

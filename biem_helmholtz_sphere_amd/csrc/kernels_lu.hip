@@ -1832,12 +1832,13 @@ __global__ void __launch_bounds__(SMALL_THREADS, (KR <= 9 ? 4 : 2)) k_small_utu(
 // Writes U11 into the upper triangle of the block and W = I - U11^{-T} as W[k][i] (the A-operand order of the streaming zgemm).
 // ---------------------------------------------------------------------------------------------
 constexpr int DIAG_LDS_CPLX = 2 * (NB * (NB + 1) / 2) + 2 * NB + NB;          // packed U rows, packed L^-1 rows, multipliers [2][64], 1 / sqrt(d)
-__global__ void __launch_bounds__(SMALL_THREADS) k_diag_utu_reg(cplx* __restrict__ A, long long lda, long long sys_stride, int j,
+constexpr int DIAG_THREADS = 1024;         // 16 waves x 4 rows: the step is bound by the instructions a wave issues for its rows
+__global__ void __launch_bounds__(DIAG_THREADS) k_diag_utu_reg(cplx* __restrict__ A, long long lda, long long sys_stride, int j,
                                                                  cplx* __restrict__ Wt, int* __restrict__ info, double rel,
                                                                  unsigned long long* __restrict__ growth) {
   extern __shared__ cplx sd[];
   __shared__ int bad;
-  constexpr int NW = SMALL_THREADS / 64, KR = NB / NW;
+  constexpr int NW = DIAG_THREADS / 64, KR = NB / NW;
   cplx* su = sd;                                   // (r, c), c >= r, at uoff(r) + c
   cplx* sy = su + NB * (NB + 1) / 2;               // (i, k), k <= i, at yoff(i) + k
   cplx* lrow = sy + NB * (NB + 1) / 2;             // [2][64] multipliers a_cj / a_cc of the current row
@@ -1969,7 +1970,7 @@ int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long 
   auto panel = [&](int j) {
     {
       ProfScope ps(PK_PANEL, st, 0.0);
-      hipLaunchKernelGGL(k_diag_utu_reg, dim3(nb), dim3(SMALL_THREADS), DIAG_LDS_CPLX * sizeof(cplx), st, A, lda, sys_stride, j, Wt, d_info, nopiv, growth);
+      hipLaunchKernelGGL(k_diag_utu_reg, dim3(nb), dim3(DIAG_THREADS), DIAG_LDS_CPLX * sizeof(cplx), st, A, lda, sys_stride, j, Wt, d_info, nopiv, growth);
     }
     // A operand W[k][i], i = row - j: the base shifted by -j rows (only rows j .. j+63 are addressed)
     if (n_cols > j + NB)

@@ -49,7 +49,8 @@ N_SEEDS = int(os.environ.get("BIEM_FUZZ_SEEDS", "96"))       # (more for a one-o
 
 
 @pytest.mark.parametrize("seed", range(N_SEEDS))
-def test_random_configuration_vs_oracle(amd, seed):
+def test_random_configuration_vs_oracle(amd, seed, monkeypatch):
+    monkeypatch.setenv("BIEM_FILL_DEDUPE_MIN", "1")               # pair classes of the fill for these 3-system calls too
     rng = np.random.default_rng(1000 + seed)
     name = list(TREES)[seed % len(TREES)]
     d, lo, hi = TREES[name]

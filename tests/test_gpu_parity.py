@@ -570,7 +570,9 @@ def test_symmetric_fill_pair_classes(amd, monkeypatch):
     """Ball pairs with the same displacement vector and the same (radius, alpha, beta) on either side share their block of the
     symmetric matrix: it is contracted once and stored to every pair of the class (k_pair_dedupe).  A 3 x 2 lattice where the classes
     are cut three ways - all balls alike; two radii; two Robin coefficients - each against the oracle, and bit for bit against the
-    same call with BIEM_FILL_NO_DEDUPE=1 (the copies are copies)."""
+    same call with BIEM_FILL_NO_DEDUPE=1 (the copies are copies).  (Classes are used from 8 systems per call on; BIEM_FILL_DEDUPE_MIN=1
+    here, and one case with 9 wavenumbers at the default.)"""
+    monkeypatch.setenv("BIEM_FILL_DEDUPE_MIN", "1")
     c = amd.create_from_branching_types("ba")
     gx, gy = np.meshgrid(np.arange(3) * 3.0, np.arange(2) * 3.0, indexing="ij")
     cen = np.stack([gx.ravel(), gy.ravel(), np.zeros(6)], -1)
@@ -595,6 +597,13 @@ def test_symmetric_fill_pair_classes(amd, monkeypatch):
             calc = amd.biem(c, centers=_dev(cen)[None], radii=_dev(rad)[None], k=_dev(ks), n_end=7, alpha=a, beta=b, uin=uin, uin_grad=ugr)
             out.append((calc.density.cpu().numpy(), calc.uscat(_dev(x.T)).cpu().numpy()))
         assert np.array_equal(out[0][0], out[1][0])
+        if np.isscalar(alpha) and rad[1] == 1.0:                         # the default threshold: 9 systems per call
+            monkeypatch.delenv("BIEM_FILL_DEDUPE_MIN")
+            k9 = np.linspace(0.8, 2.1, 9); d9 = np.repeat(dirs[:, :1], 9, axis=1)
+            uin9, ugr9 = amd.plane_wave(k=_dev(k9), direction=_dev(d9))
+            dens9 = amd.biem(c, centers=_dev(cen)[None], radii=_dev(rad)[None], k=_dev(k9), n_end=7, alpha=alpha, beta=beta, uin=uin9, uin_grad=ugr9).density.cpu().numpy()
+            assert np.array_equal(dens9[0], out[0][0][0]) or np.max(np.abs(dens9[0] - out[0][0][0])) < 1e-12 * np.max(np.abs(dens9[0]))
+            monkeypatch.setenv("BIEM_FILL_DEDUPE_MIN", "1")
         for i, k in enumerate(ks):
             uo, go = O.plane_wave(k, dirs[:, i])
             res = O.solve_biem("ba", centers=cen, radii=rad, k=k, n_end=7, alpha=np.ravel(alpha) if not np.isscalar(alpha) else alpha,
