@@ -84,7 +84,7 @@ int launch_density(const biem_plan* p, int nb, int B, int nrhs, const double* d_
 // the complex-symmetric form A~ = R W^H M W R^-1 in the plan's internal slot order, written only where the L D L^T factorisation
 // reads it (lower triangle + diagonal 64 x 64 tiles); fill_sym_bytes = those bytes per system
 // FillDedupe (optional): per-ball radii [B], alpha [B], beta [B] (complex) shared by all systems of the call.  Ball pairs with the
-// same displacement vector and the same (radius, alpha, beta) on either side have IDENTICAL blocks of A~ (translation invariance of
+// same displacement vector (to the rounding of the subtraction) and the same (radius, alpha, beta) on either side have IDENTICAL blocks of A~ (translation invariance of
 // (S|R)): the block is contracted once and stored to every such pair (lattices of equal spheres: cfg 3 has 24 distinct blocks
 // among its 120 pairs).  nullptr: every pair on its own (batched geometry or per-system alpha / beta).
 struct FillDedupe { const double* radii; const double* alpha; const double* beta; };

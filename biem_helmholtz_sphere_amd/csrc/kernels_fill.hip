@@ -446,19 +446,25 @@ __global__ void __launch_bounds__(256) k_pair_dedupe(int B, int d, int npairs, c
     for (int i = 0; i < d; ++i) disp[p * d + i] = centers[bp * d + i] - centers[b * d + i];
   }
   __syncthreads();
+  // displacements equal up to the rounding of the subtraction (a lattice with a pitch that is no binary fraction: 2.1 - 1.4 and
+  // 1.4 - 0.7 differ in the last place): 32 ulp of the largest coordinate; an exact lattice matches bit for bit either way
+  double cmax = 0.0;
+  for (int e = 0; e < B * d; ++e) cmax = fmax(cmax, fabs(centers[e]));
+  const double tol = 32.0 * 2.220446049250313e-16 * cmax;
   for (int p = tid; p < npairs; p += 256) {
     int r = p;
     const int kp = key[p];
     for (int q = 0; q < p; ++q) {
       if (key[q] != kp) continue;
       bool same = true;
-      for (int i = 0; i < d; ++i) same = same && (disp[q * d + i] == disp[p * d + i]);
+      for (int i = 0; i < d; ++i) same = same && (fabs(disp[q * d + i] - disp[p * d + i]) <= tol);
       if (same) { r = q; break; }
     }
     rep[p] = r; cnt[p] = 0;
   }
   __syncthreads();
   if (tid == 0) {
+    for (int p = 0; p < npairs; ++p) if (rep[p] != p) rep[p] = rep[rep[p]];     // (near-equality need not be transitive: resolve chains; rep[q], q < p, is final)
     for (int p = 0; p < npairs; ++p) cnt[rep[p]]++;
     int nrep = 0, pos = 0;
     for (int p = 0; p < npairs; ++p)
