@@ -201,8 +201,9 @@ int biem_solve(const biem_plan* plan, int nb, int B, int nrhs, const double* d_k
  * factorisation without interchanges (biem_sym_factor_solve), back-transform, density.  d_info[s] < 0: a diagonal pivot was rejected (see biem_ldlt_factor_solve) - the caller
  * re-solves those systems with biem_solve.  Same arguments and workspace as biem_solve.
  * With geom_batched = 0 and ab_batched = 0 the fill contracts the block of ball pairs that share their displacement vector and
- * their (radius, alpha, beta) on either side once and stores it to each of them (identical blocks by translation invariance; the
- * densities are bit for bit those of the pair-by-pair fill); systems of at most 128 unknowns (N + nrhs <= 128) are factorised and
+ * their (radius, alpha, beta) on either side once and stores it to each of them (identical blocks by translation invariance;
+ * displacements are matched to the rounding of the subtraction, so on an exactly representable lattice the densities are bit for bit
+ * those of the pair-by-pair fill, otherwise equal to rounding); systems of at most 128 unknowns (N + nrhs <= 128) are factorised and
  * solved by one launch. */
 int biem_solve_ldlt(const biem_plan* plan, int nb, int B, int nrhs, const double* d_k /*c128*/, const double* d_eta,
                     const double* d_centers, const double* d_radii, int geom_batched, const double* d_alpha, const double* d_beta,
