@@ -426,16 +426,22 @@ def _validate_biem_inputs(c, centers, radii, k, eta, alpha, beta) -> Tuple[int, 
     return tuple(batch)
 
 
-def _any(a: Any) -> bool:
-    return bool(a.any()) if isinstance(a, (torch.Tensor, np.ndarray)) else bool(np.any(a))
+def _host_array(a: Any) -> np.ndarray:
+    """Any accepted input (torch tensor on any device, NumPy array, list, scalar) as a NumPy array on the host."""
+    if isinstance(a, torch.Tensor):
+        return a.detach().cpu().numpy()
+    return np.asarray(a)
 
 
 def _warn_biem_inputs(k: Any, eta: Any) -> None:
-    """The two UserWarnings of reference :269-285 (texts verbatim, missing blanks included), on the caller's arrays
-    (NumPy or torch, any device): eta == 0 somewhere; Im k < 0 or eta Re k < 0 somewhere.  (The reference's own test of the
-    second one, :278-280, guards the Im k term with "eta is not castable to float64", which is never true once the complex-eta
-    check above it has passed, so there only eta Re k < 0 can fire; here the condition the message states is checked.)"""
-    if eta is not None and _any(eta == 0):
+    """The two UserWarnings of reference :269-285 (texts verbatim, missing blanks included): eta == 0 somewhere; Im k < 0 or
+    eta Re k < 0 somewhere.  Like the reference, which warns after ``xp.asarray(eta)``, the test runs on CONVERTED arrays, so
+    k and eta may mix torch tensors (any device), NumPy arrays, lists and scalars.  (The reference's own test of the second
+    one, :278-280, guards the Im k term with "eta is not castable to float64", which is never true once the complex-eta check
+    above it has passed, so there only eta Re k < 0 can fire; here the condition the message states is checked.)"""
+    k_h = _host_array(k)
+    eta_h = None if eta is None else _host_array(eta)
+    if eta_h is not None and bool(np.any(eta_h == 0)):
         warnings.warn(
             "The solution may be incorrect"
             "if k is an eigenvalue for laplacian"
@@ -444,8 +450,8 @@ def _warn_biem_inputs(k: Any, eta: Any) -> None:
             UserWarning,
             stacklevel=4,
         )
-    k_re, k_im = (k.real, k.imag) if _is_complex(k) else (k, None)
-    bad = (k_im is not None and _any(k_im < 0)) or _any((k_re if eta is None else eta * k_re) < 0)
+    k_re = k_h.real
+    bad = (np.iscomplexobj(k_h) and bool(np.any(k_h.imag < 0))) or bool(np.any((k_re if eta_h is None else eta_h * k_re) < 0))
     if bad:
         warnings.warn("The solution may be incorrectif not (Im k >= 0 and eta Re k >= 0).", UserWarning, stacklevel=4)
 
@@ -659,12 +665,16 @@ def biem(
                 # torch's allocator).  The per-system kernels of the LU (panel strips, diagonal-block inverses, back
                 # substitution) are latency-bound on ONE CU per system, so they cost the same for 32 or 256 systems.
                 per = max(1, int(lib.biem_solve_workspace_bytes(plan.handle, 1, B, nrhs, 1)))
-                if nb * per <= (1 << 30):
+                if nb * per <= (1 << 30) and not os.environ.get("BIEM_MAX_RESIDENT_BYTES"):
                     chunk = nb                     # small jobs: everything resident, no memory query (it costs more than the solve)
                 else:
                     free, _total = torch.cuda.mem_get_info(dev)
                     avail = free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-                    chunk = max(1, min(nb, 32768, int(0.85 * avail) // per))      # 32768: grid dimension of the per-system kernels
+                    budget = int(0.85 * avail)
+                    cap = os.environ.get("BIEM_MAX_RESIDENT_BYTES")      # a drop-in inside a larger torch program: bound the workspace
+                    if cap:
+                        budget = min(budget, max(int(float(cap)), per))
+                    chunk = max(1, min(nb, 32768, budget // per))      # 32768: grid dimension of the per-system kernels
             wbytes = int(lib.biem_solve_workspace_bytes(plan.handle, nb, B, nrhs, chunk))
             work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
             density_t = torch.empty((nb, nrhs, B, H), dtype=torch.complex128, device=dev)

@@ -85,10 +85,28 @@ def load() -> C.CDLL:
 
         from . import _build
 
-        with open(LIB_PATH + ".lock", "w") as lk:
-            fcntl.flock(lk, fcntl.LOCK_EX)
+        import contextlib
+        import warnings
+
+        # A read-only install (or a package shipped without csrc/) must still load a library that exists: the lock file and
+        # the staleness test are best effort there.  A different BIEM_HIPCC_FLAGS in the environment is part of the hash; it is
+        # an experiment switch of the build script, never set by the product.
+        try:
+            lk = open(LIB_PATH + ".lock", "a")
+        except OSError:
+            lk = None
+        with (lk if lk is not None else contextlib.nullcontext()):
+            if lk is not None:
+                fcntl.flock(lk, fcntl.LOCK_EX)
             missing = not os.path.exists(LIB_PATH)
-            if missing or _build.is_stale():
+            try:
+                stale = missing or _build.is_stale()
+            except OSError as e:              # no sources to compare with: take the library as it is
+                if missing:
+                    raise BiemLibraryError(f"{LIB_PATH} is missing and the sources to build it are not readable ({e}). "
+                                           "This package has no CPU fallback.") from e
+                stale = False
+            if stale:
                 try:
                     _build.build(force=True)       # not a fallback: the same HIP library, compiled now
                 except Exception as e:  # noqa: BLE001
@@ -98,8 +116,6 @@ def load() -> C.CDLL:
                             "`python -m biem_helmholtz_sphere_amd._build` (hipcc --offload-arch=gfx950). "
                             "This package has no CPU fallback."
                         ) from e
-                    import warnings
-
                     warnings.warn(f"{LIB_PATH} was built from other sources than this checkout's csrc/ (hash "
                                   f"{_build.built_hash()} vs {_build.source_hash()}) and could not be rebuilt: {e}", RuntimeWarning)
             lib = C.CDLL(LIB_PATH)

@@ -310,7 +310,7 @@ static int solve_impl(const biem_plan* plan, int nb, int B, int nrhs, const doub
       rc = launch_sym_rhs(plan, c, B, nrhs, L.n_pad, tb, A, L.lda, L.sys_stride, false, st);
       if (rc) return rc;
       // growth check of the factorisation: max |A~| >= 1 (its diagonal is exactly 1), so 1 is a valid, conservative reference
-      // (a system is handed to the pivoted LU when max |U| exceeds 1e3 x this lower bound); saves a pass over the matrix
+      // (a system is handed to the pivoted LU when max |u_ii u_ic| exceeds GROWTH_MAX = 200 x this lower bound); saves a pass over the matrix
       rc = lu_growth_init(Pw, c, L.n_pad, 1.0, st);
       if (rc) return rc;
       amax_ready = true;

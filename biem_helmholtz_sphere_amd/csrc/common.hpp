@@ -81,8 +81,8 @@ int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const doub
                 void* d_work, size_t work_bytes, hipStream_t st);
 int launch_density(const biem_plan* p, int nb, int B, int nrhs, const double* d_x, long long sys_stride, long long elem_stride,
                    long long rhs_stride, const double* d_tab, double* d_density, hipStream_t st, bool slot_order = false);
-// the complex-symmetric form A~ = R W^H M W R^-1 in the plan's internal slot order, written only where the L D L^T factorisation
-// reads it (lower triangle + diagonal 64 x 64 tiles); fill_sym_bytes = those bytes per system
+// the complex-symmetric form A~ = R W^H M W R^-1 in the plan's internal slot order, written only where the U^T U factorisation in row
+// form (launch_sym_factor_solve) reads it (UPPER triangle + diagonal 64 x 64 tiles); fill_sym_bytes = those bytes per system
 // FillDedupe (optional): per-ball radii [B], alpha [B], beta [B] (complex) shared by all systems of the call.  Ball pairs with the
 // same displacement vector (to the rounding of the subtraction) and the same (radius, alpha, beta) on either side have IDENTICAL blocks of A~ (translation invariance of
 // (S|R)): the block is contracted once and stored to every such pair (lattices of equal spheres: cfg 3 has 24 distinct blocks

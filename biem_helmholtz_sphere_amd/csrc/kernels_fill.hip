@@ -150,7 +150,8 @@ __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int
   __shared__ cplx sH[kMaxRad * 2 + 6];
   int pair = blockIdx.x, s = blockIdx.y;
   int b = pair / B, bp = pair % B;
-  // the general fill derives block (bp, b) from (b, bp), b < bp; the symmetric fill forms the LOWER blocks (b > bp) directly
+  // both fills contract the blocks b < bp (the general fill derives block (bp, b) from (b, bp) by the parity sign, the symmetric
+  // fill writes the upper triangle only); lower = 1 (tables of the pairs b > bp instead) is kept for tests
   if (lower ? b <= bp : b >= bp) return;
   const double* cb = centers + ((geom_batched ? (size_t)s * B : 0) + b) * d;
   const double* cp = centers + ((geom_batched ? (size_t)s * B : 0) + bp) * d;
@@ -233,10 +234,12 @@ __global__ void __launch_bounds__(FILL_THREADS) k_fill(int H, int H2, int n_end,
                                                         const uint32_t* __restrict__ ptr, const double* __restrict__ coef,
                                                         const uint16_t* __restrict__ tidx, const cplx* __restrict__ T,
                                                         const cplx* __restrict__ tab, int scaling, cplx* __restrict__ A,
-                                                        long long lda, long long sys_stride) {
+                                                        long long lda, long long sys_stride, int table_global) {
   extern __shared__ char smem[];
-  cplx* sT = (cplx*)smem;                               // [H2] pair table T_{b,bp}
-  cplx* sC = sT + H2;                                   // [H] column factors of the partner ball bp
+  // table_global: the pair table is read where it lies (global memory, served by L2) - orders whose table does not fit LDS; the
+  // generic pointer sT then addresses global memory and nothing is staged
+  cplx* const sTl = (cplx*)smem;                        // [H2] pair table T_{b,bp}
+  cplx* sC = table_global ? sTl : sTl + H2;             // [H] column factors of the partner ball bp
   cplx* sC2 = sC + H;                                   // [H] column factors of the owner ball b (mirrored block)
   double* sCoef = (double*)(sC2 + H);                   // [chunk_terms_max]
   uint32_t* sPtr = (uint32_t*)(sCoef + chunk_terms_max);   // [chunk_ents_max + 1], relative to the chunk's first term
@@ -281,7 +284,8 @@ __global__ void __launch_bounds__(FILL_THREADS) k_fill(int H, int H2, int n_end,
       cplx* Ab = As + ((size_t)b * H) * lda + (size_t)bp * H;     // block (b, bp)
       cplx* Am = As + ((size_t)bp * H) * lda + (size_t)b * H;     // block (bp, b)
       __syncthreads();                                   // previous partner's table no longer in use
-      for (int l = tid; l < H2; l += FILL_THREADS) sT[l] = Tp[l];
+      const cplx* sT = table_global ? Tp : sTl;
+      if (!table_global) for (int l = tid; l < H2; l += FILL_THREADS) sTl[l] = Tp[l];
       for (int hp = tid; hp < H; hp += FILL_THREADS) sC[hp] = colfac(tbp, hp);
       __syncthreads();
       auto put = [&](int e, double sr, double si) {
@@ -372,16 +376,16 @@ int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const doub
                        p->d_deg2, B, (const cplx*)d_k, d_centers, geom_batched, T, 0, 0, nullptr, 0);
     BIEM_LAUNCHCHK();
   }
-  size_t shm = (size_t)(p->H2 + 2 * H) * sizeof(cplx) + (size_t)p->chunk_terms_max * 10 + (size_t)(p->chunk_ents_max + 1) * 4 + 16;
+  size_t shm = (size_t)((p->fill_table_global ? 0 : p->H2) + 2 * H) * sizeof(cplx) + (size_t)p->chunk_terms_max * 10 + (size_t)(p->chunk_ents_max + 1) * 4 + 16;
   if (shm > 160 * 1024 || (p->chunk_terms_max == 0 && p->coef.size() > 0)) {
-    set_error("biem_fill: tables do not fit LDS (H2=%d, chunk terms=%d)", p->H2, p->chunk_terms_max);
+    set_error("biem_fill: tables do not fit LDS (H=%d, H2=%d, chunk terms=%d)", H, p->H2, p->chunk_terms_max);
     return BIEM_ERR_UNSUPPORTED;
   }
   BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
   const int nchunks = (int)p->chunk_ent.size() - 1;
   hipLaunchKernelGGL(k_fill, dim3(nchunks, (B + 1) / 2, nb), dim3(FILL_THREADS), shm, st, H, p->H2, p->n_end, B, p->d_deg, p->d_chunk_ent,
                      p->chunk_terms_max, p->chunk_ents_max, p->d_ptr, p->d_coef, p->d_tidx16, T, (const cplx*)d_tab, scaling,
-                     (cplx*)d_A, lda, sys_stride);
+                     (cplx*)d_A, lda, sys_stride, p->fill_table_global ? 1 : 0);
   BIEM_LAUNCHCHK();
   if (n_pad > N) {
     hipLaunchKernelGGL(k_fill_pad, dim3(64, nb), dim3(256), 0, st, N, n_pad, (cplx*)d_A, lda, sys_stride);
@@ -778,6 +782,7 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
     if (need > work_bytes) { set_error("biem_fill (symmetric, systems in lanes): workspace too small for %d systems", nb); return BIEM_ERR_ARG; }
     cplx* Qt = T + (size_t)npairs * p->H2 * nbp;
     const size_t shm = (size_t)(p->schunk_terms_max + 1) * 12 + (size_t)(4 * p->schunk_pairs_max + 1) * 4 + (size_t)p->schunk_pairs_max * 12 + 16;
+    if (p->H2 > 65536) { set_error("biem_fill (symmetric, systems in lanes): n_end=%d has %d table labels, the 16-bit term indices hold 65536", p->n_end, p->H2); return BIEM_ERR_UNSUPPORTED; }
     if (shm > 64 * 1024 || (size_t)p->H2 * 64 >= (1ull << 32)) { set_error("biem_fill (symmetric, systems in lanes): a unit pair of n_end=%d has %d terms", p->n_end, p->schunk_terms_max); return BIEM_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2, p->d_deg2, B,
                        (const cplx*)d_k, d_centers, geom_batched, T, 0, nbp, nullptr, 0);

@@ -123,11 +123,11 @@ __global__ void __launch_bounds__(256) k_uscat(int tree, int d, int H, int n_end
   const bool bad = !far && sBad;
   if (per_ball) {
     for (int b = threadIdx.x; b < B; b += 256)
-      out[((size_t)p * nb + s) * B + b] = bad ? make_double2(qnan, qnan) : sBall[b];
+      out[((size_t)p * nb + s) * B + b] = bad ? make_double2(qnan, 0.0) : sBall[b];
   } else if (threadIdx.x == 0) {
     double ar = 0.0, ai = 0.0;
     for (int b = 0; b < B; ++b) { ar += sBall[b].x; ai += sBall[b].y; }
-    out[(size_t)p * nb + s] = bad ? make_double2(qnan, qnan) : make_double2(ar, ai);
+    out[(size_t)p * nb + s] = bad ? make_double2(qnan, 0.0) : make_double2(ar, ai);
   }
 }
 
@@ -344,8 +344,8 @@ __global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, con
   const double qnan = __longlong_as_double(0x7ff8000000000000LL);
   if (p >= P) return;
   if (per_ball) {
-    if (bad) for (int b = 0; b < B; ++b) out[((size_t)p * nb + s) * B + b] = make_double2(qnan, qnan);
-  } else out[(size_t)p * nb + s] = bad ? make_double2(qnan, qnan) : make_double2(tr, ti);
+    if (bad) for (int b = 0; b < B; ++b) out[((size_t)p * nb + s) * B + b] = make_double2(qnan, 0.0);
+  } else out[(size_t)p * nb + s] = bad ? make_double2(qnan, 0.0) : make_double2(tr, ti);
 }
 
 int launch_uscat(const biem_plan* p, int nb, int B, int P, const double* d_k, const double* d_eta, const double* d_centers,

@@ -276,7 +276,11 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
   for (size_t i = 0; i < p->tidx.size(); ++i) p->tidx16[i] = (uint16_t)p->tidx[i];
   {
     const int max_ents = 1024;                                     // = FILL_THREADS of the fill kernel: one entry per thread
-    const long long budget = 150 * 1024 - (long long)(p->H2 + 2 * H) * 16 - (long long)(max_ents + 1) * 4 - 64;
+    long long budget = 150 * 1024 - (long long)(p->H2 + 2 * H) * 16 - (long long)(max_ents + 1) * 4 - 64;
+    // large orders (3-D n_end >= 40, 4-D >= 15): the pair table no longer leaves room for a useful slice of the term list - the
+    // kernel then reads the pair table from global memory (L2) and LDS holds only the column factors and the term slice
+    p->fill_table_global = budget < 2048 * 10;
+    if (p->fill_table_global) budget = 150 * 1024 - (long long)(2 * H) * 16 - (long long)(max_ents + 1) * 4 - 64;
     long long cap_terms = budget > 0 ? budget / 10 : 0;            // 8-byte coefficient + 2-byte table index per term
     if (cap_terms > 16384) cap_terms = 16384;
     const long long total = (long long)H * H;

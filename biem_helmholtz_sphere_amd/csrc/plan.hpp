@@ -22,6 +22,7 @@ struct biem_plan {
   std::vector<int> chunk_ent;               // fill chunks: entries e = h*H + h' in [chunk_ent[c], chunk_ent[c+1]); sized to the LDS budget
   int chunk_terms_max = 0;                  // largest number of terms in one chunk
   int chunk_ents_max = 0;                   // largest number of entries in one chunk
+  bool fill_table_global = false;           // general fill: the pair table stays in global memory (it does not fit LDS beside the term slice)
   // the symmetric (real-harmonic) fill: unit pairs (u, u') in row-major order, four term lists ("slots") per pair for the entries
   // (h,h'), (h,p'), (p,h'), (p,p') of the units (h,p), (h',p') - empty where h == p or h' == p' - so one thread forms a whole
   // 2 x 2 block of R W^H M W R^-1.  Internal order of the unknowns of a ball in that path: the U "cosine" combinations first

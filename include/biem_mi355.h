@@ -49,7 +49,9 @@ extern "C" {
 #define BIEM_FILL_SYMMETRIC 2    /* A~ = R W^H M W R^-1, complex symmetric (W: unitary map to real harmonics, R = diag(1/sqrt(gj gh))):
                                     what the symmetric path factors.  Rows / columns of a ball in the internal slot order of
                                     biem_plan_symmetric_order; ONLY the upper triangle and the diagonal 64 x 64 tiles are written
-                                    (n_pad must be a multiple of 64, lda >= n_pad); everything else is left untouched */
+                                    (n_pad must be a multiple of 64, lda >= n_pad); everything else is left untouched.  That is the input of
+                                    biem_sym_factor_solve (row form, upper triangle) ONLY: biem_ldlt_factor / biem_ldlt_factor_solve read the
+                                    LOWER triangle, which this fill does not write */
 
 /* uscat flags */
 #define BIEM_USCAT_FAR_FIELD 1

@@ -226,3 +226,61 @@ def test_order_ceilings_of_the_fill(amd, golden_dir):
         assert abs(got - want) < 1e-9 * max(1.0, abs(want)), (k, got, want)
     with pytest.raises(L.BiemLibraryError, match="exceeds the built table size"):
         run("a", 161, 1.0)
+
+
+@pytest.mark.parametrize("tree,n_end,ks", [("ba", 43, (2.0, 10.0)), ("bba", 15, (2.0, 6.0))])
+def test_close_spheres_beyond_the_lds_ceiling_fall_back_to_pivoted_lu(amd, monkeypatch, tree, n_end, ks):
+    """The reference hands EVERY system to a pivoted dense solve (_biem.py:797).  Two unit spheres 0.04 apart at orders whose general
+    pair table does not fit LDS (3-D n_end 43, 4-D n_end 15): (1) the default path, whatever it decides per system; (2) every system
+    rejected by the symmetric factorisation (BIEM_LDLT_PIVOT_REL = 1e30), i.e. re-filled in the general form - pair table read
+    from global memory - and solved by the pivoted LU.  Both against the oracle (numpy.linalg.solve of the reference-scaled matrix)."""
+    from biem_helmholtz_sphere_amd import _biem as impl
+
+    tr = O.tree(tree)
+    d = tr.d
+    cen = np.zeros((2, d))
+    cen[0, 1], cen[1, 1] = 1.02, -1.02
+    e0 = np.zeros(d)
+    e0[0] = 1.0
+    x = _probes(d, 4.0)
+    c = amd.create_from_branching_types(tree)
+    ks = np.asarray(ks)
+    dirs = np.zeros((d, len(ks)))
+    dirs[0] = 1.0
+    uo = []
+    for k in ks:
+        uin_o, _ = O.plane_wave(float(k), e0)
+        uo.append(O.uscat(O.solve_biem(tree, centers=cen, radii=np.ones(2), k=float(k), n_end=n_end, uin=uin_o), x))
+    uo = np.stack(uo, -1)
+
+    def run():
+        uin, _ = amd.plane_wave(k=_dev(ks), direction=_dev(dirs))
+        calc = amd.biem(c, centers=_dev(cen)[None], radii=_dev(np.ones(2))[None], k=_dev(ks), eta=_dev(np.ones(len(ks))), n_end=n_end, uin=uin)
+        return calc.uscat(_dev(x.T)).cpu().numpy(), dict(impl._last_solve_stats)
+
+    u, st = run()
+    assert st["ldlt_systems"] == len(ks)
+    assert np.max(np.abs(u - uo) / np.abs(uo)) < 1e-10, st
+    monkeypatch.setenv("BIEM_LDLT_PIVOT_REL", "1e30")
+    u, st = run()
+    assert st["lu_systems"] == len(ks) > 0
+    assert np.max(np.abs(u - uo) / np.abs(uo)) < 1e-10
+
+
+def test_matrix_attribute_beyond_the_lds_ceiling(amd):
+    """`matrix` (reference scaling, _biem.py:792,818) at 3-D n_end = 43 - the general pair table (H2 = 85^2 entries) no longer fits
+    LDS and is read from global memory - element-wise against the oracle's assembly."""
+    tree, n_end, k, eta = "ba", 43, 1.3, 0.7
+    tr = O.tree(tree)
+    cen = np.array([[0.0, 1.3, 0.2], [0.3, -1.4, -0.1]])
+    rad = np.array([1.0, 0.8])
+    alpha, beta = 1.0 + 0.25j, 0.4 - 0.1j
+    c = amd.create_from_branching_types(tree)
+    calc = amd.biem(c, centers=_dev(cen), radii=_dev(rad), k=_dev(k), eta=_dev(eta), n_end=n_end, alpha=alpha, beta=beta)
+    M = calc.matrix.cpu().numpy()
+    H = tr.n_harm(n_end)
+    assert M.shape == (2, H, 2, H)
+    A, _ = O.assemble(tr, n_end, k, eta, cen, rad, np.full(2, alpha), np.full(2, beta))
+    nz = np.abs(A) > 1e-200
+    assert np.max(np.abs(M - A)[nz] / np.abs(A)[nz]) < 5e-11
+    assert np.all(M[~nz] == 0)

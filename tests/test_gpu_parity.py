@@ -1002,6 +1002,24 @@ def test_sharded_solve_on_rccl_world_size_one(amd):
         plain = amd.biem(c, centers=cen[None], radii=rad[None], k=ks, n_end=5, uin=uin)
         assert full.shape == plain.density.shape and torch.equal(full, plain.density)
         assert torch.equal(res.density, plain.density)
+        # BASELINE config 5's shape in small: a (k, eta) batch of 4 x 3 systems, d = 4 'bba', 8 balls on the 2 x 4 grid, per-ball Robin
+        # coefficients shared by the batch - the flattened batch is what the rank solves, the gathered density has the 2-D batch shape
+        c4 = amd.create_from_branching_types("bba")
+        x0, x1 = np.meshgrid(np.arange(2) * 4.0 - 2.0, np.arange(4) * 4.0 - 6.0, indexing="ij")
+        cen4 = np.zeros((8, 4)); cen4[:, 0], cen4[:, 1] = x0.ravel(), x1.ravel()
+        k2, e2 = _dev(np.linspace(0.5, 4.0, 4))[:, None], _dev(np.linspace(0.25, 4.0, 3))[None, :]
+        d4 = np.zeros((4, 12)); d4[0] = 1.0
+        al = _dev(np.linspace(1.0, 1.7, 8), torch.complex128)[None, None, :]
+
+        def incident4(k_loc, sl):
+            return amd.plane_wave(k=k_loc, direction=_dev(d4[:, sl]))
+
+        res, full = _dist.biem_sharded(c4, centers=_dev(cen4), radii=_dev(np.ones(8)), k=k2, eta=e2, alpha=al, beta=0.25, n_end=4, incident=incident4,
+                                       device=torch.device("cuda", 0))
+        kf, ef = k2.expand(4, 3).reshape(12), e2.expand(4, 3).reshape(12)
+        uin, ugr = amd.plane_wave(k=kf, direction=_dev(d4))
+        plain = amd.biem(c4, centers=_dev(cen4)[None], radii=_dev(np.ones(8))[None], k=kf, eta=ef, alpha=al[0], beta=0.25, n_end=4, uin=uin, uin_grad=ugr)
+        assert full.shape == (4, 3, 8, 30) and torch.equal(full.reshape(12, 8, 30), plain.density)
     finally:
         dist.destroy_process_group()
 

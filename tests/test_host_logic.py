@@ -94,8 +94,21 @@ def test_user_warnings_of_the_input_check():
 
     with pytest.warns(UserWarning, match="eta Re k >= 0"):
         w(torch.tensor([1.0, 2.0]), torch.tensor([-1.0, 1.0]))
+    # mixed containers (the reference warns after xp.asarray): list eta, torch k with NumPy eta, NumPy k with torch eta
+    with pytest.warns(UserWarning, match="Neumann boundary condition"):
+        w(np.asarray([1.0, 2.0]), [0.0, 1.0])
+    with pytest.warns(UserWarning, match="Neumann boundary condition"):
+        w(torch.tensor([1.0, 2.0]), np.asarray([1.0, 0.0]))
+    with pytest.warns(UserWarning, match="eta Re k >= 0"):
+        w(torch.tensor([1.0, 2.0]), [1.0, -2.0])
+    with pytest.warns(UserWarning, match="eta Re k >= 0"):
+        w(np.asarray([1.0, 2.0]), torch.tensor([-1.0, 1.0]))
+    with pytest.warns(UserWarning, match="eta Re k >= 0"):
+        w(torch.tensor([1.0 - 0.5j, 2.0]), np.asarray([1.0, 1.0]))
     with warnings.catch_warnings():
         warnings.simplefilter("error")
+        w(torch.tensor([1.0, 2.0]), np.asarray([1.0, 3.0]))
+        w(torch.tensor([1.0, 2.0]), [1.0, 3.0])
         w(np.asarray([0.5, 8.0]), None)
         w(np.asarray(1.0 + 0.3j), np.asarray(2.0))
         w(torch.tensor([0.5, 8.0]), torch.tensor([1.0, 1.0]))
