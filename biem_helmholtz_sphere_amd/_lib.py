@@ -31,6 +31,7 @@ SIGNATURES = {
     "biem_plan_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_ll)]),
     "biem_plan_labels": (_i, [_vp, _vp, _vp]),
     "biem_plan_symmetric_order": (_i, [_vp, _vp, _vp]),
+    "biem_plan_fill_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "biem_plan_quadrature": (_i, [_vp, _vp, _vp]),
     "biem_plan_projection": (_i, [_vp, _vp]),
     "biem_plan_terms": (_i, [_vp, _vp, _vp, _vp]),

@@ -100,6 +100,16 @@ int biem_plan_symmetric_order(const biem_plan* plan, int* h_partner, int* h_slot
   return BIEM_OK;
 }
 
+int biem_plan_fill_info(const biem_plan* plan, int* n_units, int* n_phases, int* reduced_ok, int* lds_rows, int* gather_ok) {
+  NEED(plan, "plan");
+  if (n_units) *n_units = plan->E;
+  if (n_phases) *n_phases = plan->NP;
+  if (reduced_ok) *reduced_ok = plan->red_lists_ok ? 1 : 0;
+  if (lds_rows) *lds_rows = plan->rchunk_rows_max;
+  if (gather_ok) *gather_ok = (plan->pair_lists_ok && plan->qchunk.size() > 1) ? 1 : 0;
+  return BIEM_OK;
+}
+
 int biem_plan_quadrature(const biem_plan* plan, double* h_y, double* h_w) {
   NEED(plan, "plan");
   if (h_y) memcpy(h_y, plan->qy.data(), plan->qy.size() * sizeof(double));

@@ -145,7 +145,9 @@ int launch_ball_tables(const biem_plan* p, int nb, int B, const double* d_k, con
 __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int H2, double Cd, const int* __restrict__ labels2,
                                                      const int* __restrict__ deg2, int B, const cplx* __restrict__ k,
                                                      const double* __restrict__ centers, int geom_batched, cplx* __restrict__ T,
-                                                     int lower, int nbp, const int* __restrict__ lin2, int H2lin) {
+                                                     int lower, int nbp, const int* __restrict__ lin2, int H2lin,
+                                                     const int* __restrict__ red_of = nullptr, const int* __restrict__ red_first = nullptr,
+                                                     const int* __restrict__ ph_mu = nullptr, int E = 0, int NP = 0) {
   __shared__ cplx sJ[kMaxRad * 2 + 6];
   __shared__ cplx sH[kMaxRad * 2 + 6];
   int pair = blockIdx.x, s = blockIdx.y;
@@ -162,6 +164,45 @@ __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int
   if (threadIdx.x == 0) radial_jh(d, n2 - 1, cscale(k[s], r), sJ, sH);
   __syncthreads();
   Dir dir = make_dir(tree, t);
+  if (red_of != nullptr) {
+    // reduced table of the entry-per-lane symmetric fill (plan.hpp): T'[e] = C_d h_{n''} x (real angular factor of the unit's first
+    // member: the harmonic at zero azimuth), then the NP phases e^{i mu . phi}
+    cplx* o = T + ((size_t)s * B * B + pair) * (size_t)(E + NP);
+    if (tree == TREE_BA) {
+      for (int m = threadIdx.x; m < n2; m += 64) {          // one lane per |mu|: the degree recurrence of Pbar_n^m once
+        double pmm = 0.70710678118654752440;
+        for (int i = 1; i <= m; ++i) pmm *= sqrt((double)(2 * i + 1) / (double)(2 * i)) * dir.s0;
+        double p0 = 0.0, p1 = pmm;
+        for (int n = m; n < n2; ++n) {
+          if (n > m) {
+            double p2;
+            if (n == m + 1) p2 = sqrt((double)(2 * m + 3)) * dir.c0 * pmm;
+            else {
+              const double a = sqrt((double)(4 * n * n - 1) / (double)(n * n - m * m));
+              const double bq = sqrt((double)((n - 1) * (n - 1) - m * m) / (double)(4 * (n - 1) * (n - 1) - 1));
+              p2 = a * (dir.c0 * p1 - bq * p0);
+            }
+            p0 = p1; p1 = p2;
+          }
+          o[red_of[n * n + n - m]] = cscale(sH[n], Cd * p1 * kInvSqrt2Pi);       // label (n, -m) is the first member of its unit
+        }
+      }
+    } else {
+      Dir d0 = dir; d0.phi = 0.0; d0.phi2 = 0.0;
+      for (int l = threadIdx.x; l < H2; l += 64) {
+        if (!red_first[l]) continue;
+        double re, im;
+        harmonic_single(tree, labels2[3 * l], labels2[3 * l + 1], labels2[3 * l + 2], d0, &re, &im);
+        o[red_of[l]] = cscale(sH[deg2[l]], Cd * re);
+      }
+    }
+    for (int i = threadIdx.x; i < NP; i += 64) {
+      double sn, cs;
+      sincos((double)ph_mu[2 * i] * dir.phi + (double)ph_mu[2 * i + 1] * dir.phi2, &sn, &cs);
+      o[E + i] = make_double2(cs, sn);
+    }
+    return;
+  }
   // nbp > 0: systems-in-lanes layout Tt[group of 64 systems][pair index of (b < bp)][l][system in group]: a group's table rows are
   // contiguous 1-KiB lines (with the systems of ALL groups in one row, the rows one group reads lie 4 KiB apart and every
   // workgroup of a fill - they all work on the same group at a time - hits the same quarter of the L2 channels)
@@ -346,6 +387,13 @@ static bool fill_sym_entry_fits(const biem_plan* p, size_t* shm_out) {
   return p->pair_lists_ok && (int)p->qchunk.size() > 1 && shm <= 160 * 1024 && p->H2lin <= 8 * 1024;
 }
 
+// the reduced-table form (k_fill_red): reduced pair table + phases, q factors and the chunk's transposed lists in LDS
+static bool fill_red_fits(const biem_plan* p, size_t* shm_out) {
+  const size_t shm = (size_t)(p->E + p->NP + 2 * p->n_end) * sizeof(cplx) + (size_t)p->rchunk_rows_max * 64 * 10 + 64;
+  if (shm_out) *shm_out = shm;
+  return p->red_lists_ok && shm <= 158 * 1024 && p->E + p->NP <= 8 * 1024;
+}
+
 // pair classes of the symmetric fill (k_pair_dedupe), behind the pair tables: nrep (+3 pad), rep_list[np], dup_ptr[np + 1], dup_bb[np]
 static size_t fill_dedupe_bytes(int B) { const size_t np = (size_t)B * (B - 1) / 2; return ((3 * np + 5) * sizeof(int) + 15) / 16 * 16; }
 constexpr int kDedupeMaxPairs = 2048;       // (the class search is quadratic in the pairs, in one workgroup)
@@ -356,7 +404,7 @@ size_t fill_workspace_bytes(const biem_plan* p, int nb, int B) {
   const size_t a = (size_t)nb * B * B * (p->H2lin > p->H2 ? p->H2lin : p->H2), nbp = (size_t)(nb + 63) / 64 * 64;
   const size_t b = ((size_t)(B * (B - 1) / 2) * p->H2 + (size_t)B * p->n_end) * nbp;
   const char* form = getenv("BIEM_FILL_FORM");
-  const bool need_sys = (form && form[0] == 's') || !fill_sym_entry_fits(p, nullptr);
+  const bool need_sys = (form && form[0] == 's') || !(fill_sym_entry_fits(p, nullptr) || fill_red_fits(p, nullptr));
   return (need_sys && b > a ? b : a) * sizeof(cplx) + fill_dedupe_bytes(B);
 }
 
@@ -616,6 +664,155 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_sym(int H, int U, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// Symmetric fill, reduced-table form (default where its tables fit LDS).  Same work split as k_fill_sym above - a workgroup owns a
+// chunk of unit pairs, one per thread, and loops over (class, system) combinations, the next combination's table prefetched into
+// registers - but the contraction reads LDS without bank conflicts and half as much of it:
+//   * the phase e^{i mu . phi} is common to all terms of an entry and leaves the sum (plan.hpp): ONE chain per list over the
+//     reduced table T'[e] (a label and its conjugate partner share an entry), the conjugate entry is conj(phase) x the same sum;
+//   * the term lists of the 64 unit pairs of a wave are stored transposed and padded to the wave's longest list: per step the wave
+//     reads 64 consecutive coefficients and 64 consecutive 16-bit indices, all trip counts are wave-uniform (no divergence, no
+//     clamped dummy terms);
+//   * consecutive lanes are consecutive column units (n', m' = -n' .. 0) and T' is laid out degree-major, so the 64 table reads of a
+//     step fall on (nearly) consecutive entries.
+// The gather form above measured 51 % of its LDS cycles as bank conflicts and 42 bytes of LDS per term and lane (profiles/r02_pmc_summary.txt).
+// ---------------------------------------------------------------------------------------------
+template <int KT>
+__global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int HR, int E, int n_end, int B, int nb, int npairs,
+                                                                const int* __restrict__ deg, const int* __restrict__ units,
+                                                                const int* __restrict__ spos, const int* __restrict__ rchunk,
+                                                                const int* __restrict__ rcrow, const int* __restrict__ rwrow, int rows_max,
+                                                                const double* __restrict__ rcoef, const uint16_t* __restrict__ ridx,
+                                                                const uint16_t* __restrict__ rphsel,
+                                                                const cplx* __restrict__ T, const cplx* __restrict__ tab,
+                                                                cplx* __restrict__ A, long long lda, long long sys_stride,
+                                                                const int* __restrict__ classes) {
+  extern __shared__ char smem[];
+  cplx* sT = (cplx*)smem;                                  // [HR = E + NP] reduced pair table + phases of the current combination
+  cplx* sQ = sT + HR;                                      // [2][n_end]: q of the row ball, q of the column ball
+  double* sCoef = (double*)(sQ + 2 * n_end);               // [rows_max][64]
+  uint16_t* sIdx = (uint16_t*)(sCoef + (size_t)rows_max * 64);   // [rows_max][64]
+  __shared__ int sW[33];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p0 = rchunk[blockIdx.x], p1 = rchunk[blockIdx.x + 1], npr = p1 - p0;
+  const int r0 = rcrow[blockIdx.x], nrows = rcrow[blockIdx.x + 1] - r0;
+  {
+    const double* gc = rcoef + (size_t)r0 * 64;
+    const uint16_t* gi = ridx + (size_t)r0 * 64;
+    for (int q = tid; q < nrows * 64; q += FILL_SYM_THREADS) { sCoef[q] = gc[q]; sIdx[q] = gi[q]; }
+    if (tid < 33) sW[tid] = rwrow[blockIdx.x * 33 + tid];
+  }
+  // this thread's unit pair (fixed for the whole kernel)
+  const bool active = tid < npr;
+  const int pi = p0 + (active ? tid : 0);
+  const int u = pi / U, v = pi - u * U;
+  const int rh = units[2 * u], rp = units[2 * u + 1], ch = units[2 * v], cp = units[2 * v + 1];
+  const bool r2 = rp != rh, c2 = cp != ch;                 // two rows / two columns in this block
+  const int row_c = u, row_s = r2 ? U + spos[u] : 0, col_c = v, col_s = c2 ? U + spos[v] : 0;
+  const int nrow = deg[rh], ncol = deg[ch];
+  const unsigned selA = rphsel[2 * (size_t)pi], selB = rphsel[2 * (size_t)pi + 1];
+  const double q2 = 0.70710678118654752440;
+  const int nrep = classes[0];
+  const int* rep_list = classes + 4;
+  const int* dup_ptr = rep_list + npairs;
+  const int* dup_bb = dup_ptr + npairs + 1;
+  const int ncomb = nrep * nb;
+#define BIEM_TN_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define BIEM_TN_DECL(k) cplx tn##k = make_double2(0.0, 0.0);
+  BIEM_TN_LIST(BIEM_TN_DECL)
+#define BIEM_TN_LOAD(k) if (k < KT) { const int l = k * FILL_SYM_THREADS + tid; tn##k = Tp_[l < HR ? l : HR - 1]; }
+#define BIEM_TN_PUT(k) if (k < KT) { const int l = k * FILL_SYM_THREADS + tid; if (l < HR) sT[l] = tn##k; }
+  auto pair_of = [&](int pr, int& b, int& bp) {           // pr-th upper pair (row ball b < column ball bp)
+    int bb = (int)((sqrtf(8.0f * (float)pr + 1.0f) + 1.0f) * 0.5f);
+    while (bb * (bb - 1) / 2 > pr) --bb;
+    while ((bb + 1) * bb / 2 <= pr) ++bb;
+    bp = bb; b = pr - bb * (bb - 1) / 2;
+  };
+  auto table_of = [&](int cb) -> const cplx* {
+    const int s = cb / nrep, pr = rep_list[cb - s * nrep];
+    int b, bp; pair_of(pr, b, bp);
+    return T + ((size_t)s * B * B + (size_t)b * B + bp) * HR;
+  };
+  int comb = blockIdx.y;
+  if (comb < ncomb) { const cplx* Tp_ = table_of(comb); BIEM_TN_LIST(BIEM_TN_LOAD) }
+  for (; comb < ncomb; comb += gridDim.y) {
+    const int s = comb / nrep, ci = comb - s * nrep, pr = rep_list[ci];
+    int b, bp; pair_of(pr, b, bp);
+    __syncthreads();                                       // the previous combination's readers are done (also orders the chunk loads)
+    BIEM_TN_LIST(BIEM_TN_PUT)
+    if (tid < 2 * n_end) {
+      const int which = tid >= n_end, n = tid - which * n_end;
+      const cplx* tb = tab + ((size_t)s * B + (which ? bp : b)) * 3 * n_end;
+      sQ[tid] = cmul(tb[n], crecip(zsqrt(cmul(tb[n], tb[n_end + n]))));     // gj / sqrt(gj gh)
+    }
+    __syncthreads();
+    if (comb + (int)gridDim.y < ncomb) { const cplx* Tp_ = table_of(comb + (int)gridDim.y); BIEM_TN_LIST(BIEM_TN_LOAD) }   // lands while this combination is contracted
+    if (wave * 64 >= npr) continue;                        // (wave-uniform) no unit pair in this wave
+    const int ra = sW[2 * wave], rb = sW[2 * wave + 1], re = sW[2 * wave + 2];     // rows of list A: [ra, rb), of list B: [rb, re)
+    double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
+    {
+      const double* cc = sCoef + lane;
+      const uint16_t* ii = sIdx + lane;
+      int r = ra;
+      for (; r + 1 < rb; r += 2) {                         // two steps per trip: both coefficient / index pairs, then both table reads
+        const double c0 = cc[r * 64], c1 = cc[(r + 1) * 64];
+        const unsigned i0 = ii[r * 64], i1 = ii[(r + 1) * 64];
+        const cplx z0 = sT[i0], z1 = sT[i1];
+        ar = fma(c0, z0.x, ar); ai = fma(c0, z0.y, ai);
+        ar = fma(c1, z1.x, ar); ai = fma(c1, z1.y, ai);
+      }
+      if (r < rb) { const double c0 = cc[r * 64]; const cplx z0 = sT[ii[r * 64]]; ar = fma(c0, z0.x, ar); ai = fma(c0, z0.y, ai); }
+      r = rb;
+      for (; r + 1 < re; r += 2) {
+        const double c0 = cc[r * 64], c1 = cc[(r + 1) * 64];
+        const unsigned i0 = ii[r * 64], i1 = ii[(r + 1) * 64];
+        const cplx z0 = sT[i0], z1 = sT[i1];
+        br = fma(c0, z0.x, br); bi = fma(c0, z0.y, bi);
+        br = fma(c1, z1.x, br); bi = fma(c1, z1.y, bi);
+      }
+      if (r < re) { const double c0 = cc[r * 64]; const cplx z0 = sT[ii[r * 64]]; br = fma(c0, z0.x, br); bi = fma(c0, z0.y, bi); }
+    }
+    if (!active) continue;
+    // entries of the 2 x 2 raw block: (h,h') = phase_A R_A, its conjugate entry conj(phase_A) R_A; (h,p') = phase_B R_B, (p,h') = conj(phase_B) R_B
+    cplx phA = sT[E + (selA >> 1)], phB = sT[E + (selB >> 1)];
+    if (selA & 1u) phA.y = -phA.y;
+    if (selB & 1u) phB.y = -phB.y;
+    const cplx RA = make_double2(ar, ai), RB = make_double2(br, bi);
+    const cplx mA = cmul(RA, make_double2(phA.x, -phA.y));
+    cplx x00 = cmul(RA, phA), x01 = (r2 && c2) ? cmul(RB, phB) : mA, x10 = (r2 && c2) ? cmul(RB, make_double2(phB.x, -phB.y)) : mA, x11 = mA;
+    if (r2) {
+      const cplx a0c = make_double2((x00.x + x10.x) * q2, (x00.y + x10.y) * q2), a1c = make_double2((x01.x + x11.x) * q2, (x01.y + x11.y) * q2);
+      const cplx d0 = make_double2((x00.x - x10.x) * q2, (x00.y - x10.y) * q2), d1 = make_double2((x01.x - x11.x) * q2, (x01.y - x11.y) * q2);
+      x00 = a0c; x01 = a1c; x10 = make_double2(-d0.y, d0.x); x11 = make_double2(-d1.y, d1.x);
+    }
+    if (c2) {
+      const cplx a0c = make_double2((x00.x + x01.x) * q2, (x00.y + x01.y) * q2), d0 = make_double2((x01.x - x00.x) * q2, (x01.y - x00.y) * q2);
+      const cplx a1c = make_double2((x10.x + x11.x) * q2, (x10.y + x11.y) * q2), d1 = make_double2((x11.x - x10.x) * q2, (x11.y - x10.y) * q2);
+      x00 = a0c; x01 = make_double2(-d0.y, d0.x); x10 = a1c; x11 = make_double2(-d1.y, d1.x);
+    }
+    const cplx scale = cmul(sQ[nrow], sQ[n_end + ncol]);
+    cplx* As = A + (size_t)s * sys_stride;
+    const int e0 = dup_ptr[ci], e1 = dup_ptr[ci + 1];
+    auto put = [&](int rslot, int cslot, cplx val) {
+      const cplx w = cmul(val, scale);
+      for (int e = e0; e < e1; ++e) {                        // every pair of the class (the representative first)
+        const int bb = dup_bb[e];
+        const int row = (bb >> 16) * H + rslot, col = (bb & 0xffff) * H + cslot;   // b < bp: strictly above the diagonal
+        As[(size_t)row * lda + col] = w;
+        if ((row >> 6) == (col >> 6)) As[(size_t)col * lda + row] = w;   // a diagonal 64 x 64 tile is read whole: mirror (A~ = A~^T)
+      }
+    };
+    put(row_c, col_c, x00);
+    if (c2) put(row_c, col_s, x01);
+    if (r2) { put(row_s, col_c, x10); if (c2) put(row_s, col_s, x11); }
+  }
+#undef BIEM_TN_LIST
+#undef BIEM_TN_DECL
+#undef BIEM_TN_LOAD
+#undef BIEM_TN_PUT
+}
+
+// ---------------------------------------------------------------------------------------------
 // Symmetric fill, systems in lanes (batches of >= 32 systems): lane = system, the wave walks the unit pairs of its chunk one
 // after the other.  Every lane of a wave then runs the SAME term list: the coefficient and the table index of a term are
 // wave-uniform (broadcast LDS reads), the pair-table row T[l][0..63] of the 64 systems is one contiguous 1-KiB load (tables
@@ -772,8 +969,12 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
   // system per lane, pair tables from L2 / Infinity Cache: bound by the ~35-70 GB/s a CU gets from there, 150 vs 92 ms per 256
   // systems at cfg 3) has no ceiling on the order and takes over where the entry form does not fit.  BIEM_FILL_FORM forces one.
   const char* form = getenv("BIEM_FILL_FORM");
-  size_t shm_entry = 0;
-  const bool entry_fits = fill_sym_entry_fits(p, &shm_entry);
+  size_t shm_entry = 0, shm_red = 0;
+  // BIEM_FILL_FORM: "red" (default where it fits) = reduced-table entry form k_fill_red, "entry" = the gather form k_fill_sym it
+  // replaced (kept for A/B runs), "sys" = systems in lanes
+  const bool red_fits = fill_red_fits(p, &shm_red);
+  const bool use_red = red_fits && !(form && (form[0] == 's' || form[0] == 'e'));
+  const bool entry_fits = use_red || fill_sym_entry_fits(p, &shm_entry);
   const bool sys_form = form ? (form[0] == 's') : !entry_fits;
   if (B > 1 && sys_form) {
     // systems in lanes.  Workspace: Tt[groups][npairs][H2][64] then Qt[groups][B][n_end][64] (fill_workspace_bytes covers it)
@@ -802,14 +1003,18 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
                        (const cplx*)T, (const cplx*)Qt, (cplx*)d_A, lda, sys_stride, getenv("BIEM_ABL_FILL_NOSTORE") ? 1 : 0);
     BIEM_LAUNCHCHK();
   } else if (B > 1) {
-    const int nchunks = (int)p->qchunk.size() - 1;
-    const size_t shm = shm_entry;
+    const int nchunks = use_red ? (int)p->rchunk.size() - 1 : (int)p->qchunk.size() - 1;
+    const size_t shm = use_red ? shm_red : shm_entry;
     if (!entry_fits) {
       set_error("biem_fill (symmetric, one unit pair per lane): tables do not fit LDS (n_end=%d: H2=%d, chunk terms=%d)", p->n_end, p->H2, p->qchunk_terms_max);
       return BIEM_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2, p->d_deg2, B,
-                       (const cplx*)d_k, d_centers, geom_batched, T, 0, 0, p->d_lin2, p->H2lin);
+    if (use_red)
+      hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2, p->d_deg2, B,
+                         (const cplx*)d_k, d_centers, geom_batched, T, 0, 0, nullptr, 0, p->d_red_of, p->d_red_first, p->d_ph_mu, p->E, p->NP);
+    else
+      hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2, p->d_deg2, B,
+                         (const cplx*)d_k, d_centers, geom_batched, T, 0, 0, p->d_lin2, p->H2lin);
     BIEM_LAUNCHCHK();
     const int npairs = B * (B - 1) / 2;
     const long long ncomb = (long long)npairs * nb;
@@ -830,7 +1035,21 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
     if (gy < 1) gy = 1;
     if (gy > ncomb) gy = ncomb;
     if (gy > 65535) gy = 65535;
-    const int kt_need = (p->H2lin + FILL_SYM_THREADS - 1) / FILL_SYM_THREADS;
+    const int HR = p->E + p->NP;
+    const int kt_need = ((use_red ? HR : p->H2lin) + FILL_SYM_THREADS - 1) / FILL_SYM_THREADS;
+#define BIEM_LAUNCH_FILL_RED(KT)                                                                                                          \
+  {                                                                                                                                       \
+    BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_fill_red<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                  \
+    hipLaunchKernelGGL(k_fill_red<KT>, dim3(nchunks, (unsigned)gy), dim3(FILL_SYM_THREADS), shm, st, H, U, HR, p->E, p->n_end, B, nb, npairs, \
+                       p->d_deg, p->d_units, p->d_spos, p->d_rchunk, p->d_rcrow, p->d_rwrow, p->rchunk_rows_max, p->d_rcoef, p->d_ridx,   \
+                       p->d_rphsel, T, (const cplx*)d_tab, (cplx*)d_A, lda, sys_stride, classes);                                        \
+  }
+    if (use_red) {
+      if (kt_need <= 1) BIEM_LAUNCH_FILL_RED(1)
+      else if (kt_need <= 2) BIEM_LAUNCH_FILL_RED(2)
+      else if (kt_need <= 4) BIEM_LAUNCH_FILL_RED(4)
+      else BIEM_LAUNCH_FILL_RED(8)
+    } else
 #define BIEM_LAUNCH_FILL_SYM(KT)                                                                                                          \
   {                                                                                                                                       \
     BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_fill_sym<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                  \
@@ -845,6 +1064,7 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
     else if (kt_need <= 6) BIEM_LAUNCH_FILL_SYM(6)
     else BIEM_LAUNCH_FILL_SYM(8)
 #undef BIEM_LAUNCH_FILL_SYM
+#undef BIEM_LAUNCH_FILL_RED
     BIEM_LAUNCHCHK();
   }
   // (no_padding: the caller's solver never reads the identity padding - the LDS-resident path of small systems)

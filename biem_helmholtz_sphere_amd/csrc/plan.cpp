@@ -372,6 +372,99 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
           p->q2ptr[((size_t)u * U + v) * 2 + 2] = (uint32_t)p->q2coef.size();
         }
       p->pair_lists_ok = ok;
+      // ---- reduced-table form: T'[e] shared by a label and its partner, one phase per list (plan.hpp) ----
+      bool rok = ok;
+      p->E = ne; p->red_of.assign(H2, 0); p->red_first.assign(H2, 0); p->red_label.assign(ne, 0);
+      for (int l = 0; l < H2 && rok; ++l) {
+        p->red_of[l] = p->lin2[l] >> 1;
+        p->red_first[l] = (l <= partner2[l]) ? 1 : 0;
+        if (l <= partner2[l]) p->red_label[p->lin2[l] >> 1] = l;
+      }
+      // phase ids: one per distinct azimuthal order vector of the first members
+      auto az_of = [&](int l, int& m1, int& m2) {
+        const int a = p->labels2[3 * l], b = p->labels2[3 * l + 1], c = p->labels2[3 * l + 2];
+        m2 = 0;
+        if (tree == TREE_A) m1 = a; else if (tree == TREE_BA) m1 = b; else if (tree == TREE_BBA) m1 = c; else { m1 = b; m2 = c; }
+      };
+      std::map<std::pair<int, int>, int> phid;
+      p->ph_mu.clear(); p->ph_of_unit.assign(ne, 0);
+      for (int e = 0; e < ne && rok; ++e) {
+        int m1, m2; az_of(p->red_label[e], m1, m2);
+        auto it = phid.find(std::make_pair(m1, m2));
+        if (it == phid.end()) { it = phid.insert(std::make_pair(std::make_pair(m1, m2), (int)phid.size())).first; p->ph_mu.push_back(m1); p->ph_mu.push_back(m2); }
+        p->ph_of_unit[e] = it->second;
+      }
+      p->NP = (int)phid.size();
+      if (p->E + p->NP > 65535 || p->NP > 32767) rok = false;
+      // per list: all terms of one kind (first members / partners / self-conjugate) and of one phase id
+      p->rphsel.assign((size_t)2 * U * U, 0);
+      auto list_sel = [&](size_t e, uint16_t& sel) {     // phase selector of entry e's list; false if the list is not uniform
+        int kind = -1, id = -1;
+        for (uint32_t q = p->ptr[e]; q < p->ptr[e + 1]; ++q) {
+          const int l = p->tidx[q], u2 = p->red_of[l];
+          const int k2 = partner2[l] == l ? 0 : (p->red_first[l] ? 1 : 2);          // 0 self, 1 first, 2 partner
+          if (kind < 0) { kind = k2; id = p->ph_of_unit[u2]; }
+          else if (kind != k2 || id != p->ph_of_unit[u2]) return false;
+        }
+        if (kind < 0) { sel = 0; return true; }            // empty list: value 0 whatever the phase
+        if (kind == 0) {                                    // self-conjugate labels: azimuthal vector 0, phase 1
+          if (p->ph_mu[2 * id] != 0 || p->ph_mu[2 * id + 1] != 0) return false;
+        }
+        sel = (uint16_t)(2 * id + (kind == 2 ? 1 : 0));
+        return true;
+      };
+      // transposed, padded lists per wave of 64 unit pairs; chunks of at most 16 waves within the LDS budget
+      p->rcoef.clear(); p->ridx.clear(); p->rchunk.assign(1, 0); p->rcrow.assign(1, 0); p->rwrow.clear(); p->rchunk_rows_max = 0;
+      const long long total_pairs = (long long)U * U;
+      const long long lds_budget = 156 * 1024 - (long long)(p->E + p->NP) * 16 - (long long)2 * n_end * 16 - 33 * 4 - 256;
+      const long long cap_rows = lds_budget > 0 ? lds_budget / (64 * 10) : 0;          // a row: 64 x (8-byte coefficient + 2-byte index)
+      std::vector<int> wr(33, 0);
+      long long crows = 0; int cw = 0;                     // rows / waves of the open chunk
+      auto close_chunk = [&](long long pair_end) {
+        for (int w = cw; w < 16; ++w) { wr[2 * w + 1] = wr[2 * w]; wr[2 * w + 2] = wr[2 * w]; }
+        for (int i = 0; i < 33; ++i) p->rwrow.push_back(wr[i]);
+        p->rchunk.push_back((int)pair_end);
+        p->rcrow.push_back((int)(p->rcoef.size() / 64));
+        if (crows > p->rchunk_rows_max) p->rchunk_rows_max = (int)crows;
+        crows = 0; cw = 0; wr.assign(33, 0);
+      };
+      for (long long w0 = 0; w0 < total_pairs && rok; w0 += 64) {
+        const int nl = (int)((total_pairs - w0 < 64) ? total_pairs - w0 : 64);
+        size_t eA[64], eB[64]; bool hasB[64];
+        uint32_t LA = 0, LB = 0;
+        for (int i = 0; i < nl; ++i) {
+          const long long pi = w0 + i; const int u = (int)(pi / U), v = (int)(pi - (long long)u * U);
+          const int h = p->units[2 * u], pp = p->units[2 * u + 1], ch = p->units[2 * v], cp = p->units[2 * v + 1];
+          eA[i] = (size_t)h * H + ch; eB[i] = (size_t)h * H + cp; hasB[i] = (pp != h) && (cp != ch);
+          uint16_t sA = 0, sB = 0;
+          rok = rok && list_sel(eA[i], sA);
+          if (hasB[i]) rok = rok && list_sel(eB[i], sB);
+          p->rphsel[2 * (size_t)pi] = sA; p->rphsel[2 * (size_t)pi + 1] = sB;
+          const uint32_t la = p->ptr[eA[i] + 1] - p->ptr[eA[i]], lb = hasB[i] ? p->ptr[eB[i] + 1] - p->ptr[eB[i]] : 0;
+          if (la > LA) LA = la;
+          if (lb > LB) LB = lb;
+        }
+        if (!rok) break;
+        if ((long long)(LA + LB) > cap_rows) { rok = false; break; }                    // one wave alone exceeds the LDS budget
+        if (cw == 16 || crows + LA + LB > cap_rows) close_chunk(w0);
+        wr[2 * cw] = (int)crows; wr[2 * cw + 1] = (int)(crows + LA); wr[2 * cw + 2] = (int)(crows + LA + LB);
+        for (int pass = 0; pass < 2; ++pass) {
+          const uint32_t L = pass ? LB : LA;
+          for (uint32_t t = 0; t < L; ++t)
+            for (int i = 0; i < 64; ++i) {
+              double cf = 0.0; uint16_t ix = 0;
+              if (i < nl && (pass == 0 || hasB[i])) {
+                const size_t e = pass ? eB[i] : eA[i];
+                if (t < p->ptr[e + 1] - p->ptr[e]) { cf = p->coef[p->ptr[e] + t]; ix = (uint16_t)p->red_of[p->tidx[p->ptr[e] + t]]; }
+              }
+              p->rcoef.push_back(cf); p->ridx.push_back(ix);
+            }
+        }
+        crows += LA + LB; ++cw;
+      }
+      if (rok && cw > 0) close_chunk(total_pairs);
+      p->red_lists_ok = rok && (int)p->rchunk.size() > 1;
+      if (!p->red_lists_ok) { p->rcoef.clear(); p->ridx.clear(); p->rchunk.assign(1, 0); p->rcrow.assign(1, 0); p->rwrow.clear(); p->rchunk_rows_max = 0; }
     }
     // chunks: the paired pair table (H2lin complex), the per-degree factors of two balls, the list pointers and the term slice share LDS
     const int max_pairs = 1024;                                    // = FILL_SYM_THREADS: one unit pair per thread
@@ -449,6 +542,16 @@ int plan_upload(biem_plan* p) {
   if ((rc = up(&p->d_q2ptr, p->q2ptr))) return rc;
   if ((rc = up(&p->d_q2coef, p->q2coef))) return rc;
   if ((rc = up(&p->d_q2idx16, p->q2idx16))) return rc;
+  if ((rc = up(&p->d_red_of, p->red_of))) return rc;
+  if ((rc = up(&p->d_red_first, p->red_first))) return rc;
+  if ((rc = up(&p->d_red_label, p->red_label))) return rc;
+  if ((rc = up(&p->d_ph_mu, p->ph_mu))) return rc;
+  if ((rc = up(&p->d_rcoef, p->rcoef))) return rc;
+  if ((rc = up(&p->d_ridx, p->ridx))) return rc;
+  if ((rc = up(&p->d_rphsel, p->rphsel))) return rc;
+  if ((rc = up(&p->d_rchunk, p->rchunk))) return rc;
+  if ((rc = up(&p->d_rcrow, p->rcrow))) return rc;
+  if ((rc = up(&p->d_rwrow, p->rwrow))) return rc;
   p->device = dev;
   return BIEM_OK;
 }
@@ -461,6 +564,8 @@ void plan_free(biem_plan* p) {
     (void)hipFree(p->d_spos); (void)hipFree(p->d_hpos); (void)hipFree(p->d_qptr); (void)hipFree(p->d_qcoef); (void)hipFree(p->d_qidx16);
     (void)hipFree(p->d_qchunk); (void)hipFree(p->d_schunk);
     (void)hipFree(p->d_lin2); (void)hipFree(p->d_q2ptr); (void)hipFree(p->d_q2coef); (void)hipFree(p->d_q2idx16);
+    (void)hipFree(p->d_red_of); (void)hipFree(p->d_red_first); (void)hipFree(p->d_red_label); (void)hipFree(p->d_ph_mu);
+    (void)hipFree(p->d_rcoef); (void)hipFree(p->d_ridx); (void)hipFree(p->d_rphsel); (void)hipFree(p->d_rchunk); (void)hipFree(p->d_rcrow); (void)hipFree(p->d_rwrow);
   }
   delete p;
 }

@@ -44,6 +44,28 @@ struct biem_plan {
   std::vector<uint16_t> q2idx16;            // indices into the paired table layout
   std::vector<int> qchunk;                  // chunks of unit pairs: [qchunk[c], qchunk[c+1]), at most FILL_SYM_THREADS pairs each
   int qchunk_terms_max = 0, qchunk_pairs_max = 0;
+  // ---- reduced-table form of the entry-per-lane symmetric fill (k_fill_sym) ----
+  // Every term of one entry (h, h') carries the same azimuthal order vector mu = m' - m, so T[l] = T'[e(l)] * e^{+-i mu.phi} with the
+  // REAL-angular-factor table T'[e] = C_d h_{n''}(k|t|) |Y_l|-amplitude shared by a label and its conjugate partner (e = unit of
+  // the label among the degree < 2 n_end - 1 labels) and the phase leaves the sum:  S(h,h') = phase * sum_p coef[p] T'[e[p]],  and
+  // the conjugate entry (p,p') is conj(phase) times the SAME sum.  One chain per list instead of two, half the table.
+  // Table row of a (pair, system): T'[0 .. E) then the NP phases e^{i mu_id . phi} of the distinct azimuthal vectors of first members.
+  int E = 0, NP = 0;                        // E = H2lin / 2 label units, NP phase ids
+  std::vector<int> red_of;                  // [H2] unit e of label l
+  std::vector<int> red_first;               // [H2] 1: l is the first member of its unit (or self-conjugate), 0: the partner
+  std::vector<int> red_label;               // [E] the first member's label index
+  std::vector<int> ph_mu;                   // [NP][2] azimuthal orders of phase id (second entry: caa only)
+  std::vector<int> ph_of_unit;              // [E] phase id of the unit's first member
+  // term lists per wave of 64 consecutive unit pairs, TRANSPOSED and padded to the wave's longest list: row r holds term number
+  // (r - start) of the 64 lanes (coefficient 0, index 0 where a lane's list has run out), so the per-step reads of a wave are
+  // contiguous (no LDS bank conflicts).  Chunk c = unit pairs [rchunk[c], rchunk[c+1]) (at most 1024 = 16 waves), its rows
+  // [rcrow[c], rcrow[c+1]); rwrow[c * 33 + 2 w + {0, 1, 2}] = first row of wave w's list A, of its list B, end (relative to the chunk).
+  bool red_lists_ok = false;
+  std::vector<double> rcoef;                // [rows][64]
+  std::vector<uint16_t> ridx;               // [rows][64] indices e into T'
+  std::vector<uint16_t> rphsel;             // [U U][2]: phase selector of list A, of list B: 2 * phase id + (1: conjugate phase)
+  std::vector<int> rchunk, rcrow, rwrow;
+  int rchunk_rows_max = 0;
   // the same lists cut into small chunks for the systems-in-lanes form of the symmetric fill (k_fill_sys: no LDS ceiling on H2)
   std::vector<int> schunk;
   int schunk_terms_max = 0, schunk_pairs_max = 0;
@@ -58,6 +80,8 @@ struct biem_plan {
   int* d_spos = nullptr; int* d_hpos = nullptr; uint32_t* d_qptr = nullptr; double* d_qcoef = nullptr; uint16_t* d_qidx16 = nullptr;
   int* d_qchunk = nullptr; int* d_schunk = nullptr;
   int* d_lin2 = nullptr; uint32_t* d_q2ptr = nullptr; double* d_q2coef = nullptr; uint16_t* d_q2idx16 = nullptr;
+  int* d_red_of = nullptr; int* d_red_first = nullptr; int* d_red_label = nullptr; int* d_ph_mu = nullptr;
+  double* d_rcoef = nullptr; uint16_t* d_ridx = nullptr; uint16_t* d_rphsel = nullptr; int* d_rchunk = nullptr; int* d_rcrow = nullptr; int* d_rwrow = nullptr;
 };
 
 namespace biem {

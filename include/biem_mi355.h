@@ -85,6 +85,11 @@ int biem_plan_labels(const biem_plan* plan, int* h_labels, int* h_deg);
  * internal position of harmonic h among its ball's H unknowns in that path: for a unit (h <= p) the "cosine" combination
  * (Y_h + Y_p)/sqrt2 sits in slot h_slot[h], the "sine" combination i (Y_p - Y_h)/sqrt2 in slot h_slot[p] */
 int biem_plan_symmetric_order(const biem_plan* plan, int* h_partner /*[H]*/, int* h_slot /*[H]*/);
+/* which forms of the symmetric fill this plan's tables admit (host information, no device needed): n_units = label units E of the
+ * reduced pair table (a degree < 2 n_end - 1 label and its conjugate partner share an entry), n_phases = distinct azimuthal phases,
+ * reduced_ok = 1 if every term list is of one kind and one phase and a wave's lists fit LDS (the default fill kernel), lds_rows =
+ * term rows (64 lanes each) of its largest chunk, gather_ok = 1 if the gather form it replaced fits */
+int biem_plan_fill_info(const biem_plan* plan, int* n_units, int* n_phases, int* reduced_ok, int* lds_rows, int* gather_ok);
 /* unit vectors y[Q][d] and weights w[Q] of the boundary-data rule (ush.expand(n=n_end)) */
 int biem_plan_quadrature(const biem_plan* plan, double* h_y, double* h_w);
 /* projection matrix W[Q][H] (complex128, host copy):  f_h = sum_q W[q][h] g(y_q),  W = w_q conj(Y_h(y_q)) */

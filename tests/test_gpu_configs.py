@@ -242,7 +242,10 @@ def test_close_spheres_beyond_the_lds_ceiling_fall_back_to_pivoted_lu(amd, monke
     cen[0, 1], cen[1, 1] = 1.02, -1.02
     e0 = np.zeros(d)
     e0[0] = 1.0
-    x = _probes(d, 4.0)
+    # probes on the circle of radius 4 (the origin of _probes lies INSIDE the 0.04 gap, 0.02 from either surface: there the series
+    # sum_n c_n h_n(1.02 k) Y_n is a sum of terms ~1e3 x its value at these orders and amplifies the rounding of the tiny high-order
+    # coefficients - 8e-9 between any two solvers - which says nothing about the solve)
+    x = _probes(d, 4.0)[1:]
     c = amd.create_from_branching_types(tree)
     ks = np.asarray(ks)
     dirs = np.zeros((d, len(ks)))

@@ -1025,7 +1025,7 @@ def test_sharded_solve_on_rccl_world_size_one(amd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["entry", "sys"])
+@pytest.mark.parametrize("form", ["red", "entry", "sys"])
 @pytest.mark.parametrize("tree,n_end,B,robin", [("a", 9, 3, False), ("ba", 6, 3, True), ("ba", 12, 2, False), ("bba", 4, 3, True), ("caa", 4, 2, False)])
 def test_symmetric_fill_vs_transformed_general_fill(amd, lib, tree, n_end, B, robin, form, monkeypatch):
     """BIEM_FILL_SYMMETRIC (what the L D L^T path factors, written once by the fused kernel) against R W^H M W R^-1 formed in

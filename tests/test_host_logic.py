@@ -38,6 +38,10 @@ def test_plan_host_tables_without_gpu():
         _lib.check(lib.biem_plan_quadrature(plan, y.ctypes.data, w.ctypes.data))
         area = {2: 2 * np.pi, 3: 4 * np.pi, 4: 2 * np.pi**2}[d.value]
         assert abs(w.sum() - area) < 1e-12 and np.allclose(np.linalg.norm(y, axis=1), 1.0)
+        # the reduced-table form of the symmetric fill: every term list of one kind and one phase (checked entry by entry at build time)
+        e, npz, rok, rows, gok = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _lib.check(lib.biem_plan_fill_info(plan, C.byref(e), C.byref(npz), C.byref(rok), C.byref(rows), C.byref(gok)))
+        assert rok.value == 1 and gok.value == 1 and 0 < npz.value <= e.value < h2.value and rows.value > 0, (tree, e.value, npz.value, rok.value, rows.value)
         lib.biem_plan_destroy(plan)
     plan = C.c_void_p()
     assert lib.biem_plan_create_host(7, 3, C.byref(plan)) == 3          # BIEM_ERR_UNSUPPORTED
