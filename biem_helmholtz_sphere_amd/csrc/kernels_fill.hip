@@ -676,6 +676,12 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_sym(int H, int U, int
 //     step fall on (nearly) consecutive entries.
 // The gather form above measured 51 % of its LDS cycles as bank conflicts and 42 bytes of LDS per term and lane (profiles/r02_pmc_summary.txt).
 // ---------------------------------------------------------------------------------------------
+#ifdef BIEM_FILL_TRACE
+__device__ unsigned long long g_fill_trace[8];
+#define BIEM_FT(i) { if (tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ft_acc[i] += now_ - ft_t; ft_t = now_; } }
+#else
+#define BIEM_FT(i)
+#endif
 template <int KT>
 __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int HR, int E, int n_end, int B, int nb, int npairs,
                                                                 const int* __restrict__ deg, const int* __restrict__ units,
@@ -735,17 +741,25 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
   };
   int comb = blockIdx.y;
   if (comb < ncomb) { const cplx* Tp_ = table_of(comb); BIEM_TN_LIST(BIEM_TN_LOAD) }
+#ifdef BIEM_FILL_TRACE
+  unsigned long long ft_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ft_t = __builtin_amdgcn_s_memtime();
+#endif
   for (; comb < ncomb; comb += gridDim.y) {
     const int s = comb / nrep, ci = comb - s * nrep, pr = rep_list[ci];
     int b, bp; pair_of(pr, b, bp);
+    BIEM_FT(0)
     __syncthreads();                                       // the previous combination's readers are done (also orders the chunk loads)
+    BIEM_FT(1)
     BIEM_TN_LIST(BIEM_TN_PUT)
+    BIEM_FT(2)
     if (tid < 2 * n_end) {
       const int which = tid >= n_end, n = tid - which * n_end;
       const cplx* tb = tab + ((size_t)s * B + (which ? bp : b)) * 3 * n_end;
       sQ[tid] = cmul(tb[n], crecip(zsqrt(cmul(tb[n], tb[n_end + n]))));     // gj / sqrt(gj gh)
     }
+    BIEM_FT(3)
     __syncthreads();
+    BIEM_FT(4)
     if (comb + (int)gridDim.y < ncomb) { const cplx* Tp_ = table_of(comb + (int)gridDim.y); BIEM_TN_LIST(BIEM_TN_LOAD) }   // lands while this combination is contracted
     if (wave * 64 >= npr) continue;                        // (wave-uniform) no unit pair in this wave
     const int ra = sW[2 * wave], rb = sW[2 * wave + 1], re = sW[2 * wave + 2];     // rows of list A: [ra, rb), of list B: [rb, re)
@@ -772,6 +786,7 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
       }
       if (r < re) { const double c0 = cc[r * 64]; const cplx z0 = sT[ii[r * 64]]; br = fma(c0, z0.x, br); bi = fma(c0, z0.y, bi); }
     }
+    BIEM_FT(5)
     if (!active) continue;
     // entries of the 2 x 2 raw block: (h,h') = phase_A R_A, its conjugate entry conj(phase_A) R_A; (h,p') = phase_B R_B, (p,h') = conj(phase_B) R_B
     cplx phA = sT[E + (selA >> 1)], phB = sT[E + (selB >> 1)];
@@ -805,12 +820,23 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
     put(row_c, col_c, x00);
     if (c2) put(row_c, col_s, x01);
     if (r2) { put(row_s, col_c, x10); if (c2) put(row_s, col_s, x11); }
+    BIEM_FT(6)
   }
+#ifdef BIEM_FILL_TRACE
+  if (tid == 0) for (int i = 0; i < 8; ++i) atomicAdd(&g_fill_trace[i], ft_acc[i]);
+#endif
 #undef BIEM_TN_LIST
 #undef BIEM_TN_DECL
 #undef BIEM_TN_LOAD
 #undef BIEM_TN_PUT
 }
+#ifdef BIEM_FILL_TRACE
+extern "C" int biem_debug_fill_trace(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fill_trace), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_fill_trace), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Symmetric fill, systems in lanes (batches of >= 32 systems): lane = system, the wave walks the unit pairs of its chunk one
