@@ -147,7 +147,8 @@ __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int
                                                      const double* __restrict__ centers, int geom_batched, cplx* __restrict__ T,
                                                      int lower, int nbp, const int* __restrict__ lin2, int H2lin,
                                                      const int* __restrict__ red_of = nullptr, const int* __restrict__ red_first = nullptr,
-                                                     const int* __restrict__ ph_mu = nullptr, int E = 0, int NP = 0) {
+                                                     const int* __restrict__ ph_mu = nullptr, int E = 0, int NP = 0,
+                                                     const cplx* __restrict__ tab = nullptr, int n_end = 0) {
   __shared__ cplx sJ[kMaxRad * 2 + 6];
   __shared__ cplx sH[kMaxRad * 2 + 6];
   int pair = blockIdx.x, s = blockIdx.y;
@@ -167,7 +168,14 @@ __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int
   if (red_of != nullptr) {
     // reduced table of the entry-per-lane symmetric fill (plan.hpp): T'[e] = C_d h_{n''} x (real angular factor of the unit's first
     // member: the harmonic at zero azimuth), then the NP phases e^{i mu . phi}
-    cplx* o = T + ((size_t)s * B * B + pair) * (size_t)(E + NP);
+    // ... and the per-degree factors q = gj / sqrt(gj gh) of the row ball b and of the column ball bp (the kernel multiplies the block by
+    // q_b[n] q_bp[n']): a table row is everything a (pair, system) combination of the fill needs, E + NP + 2 n_end complex numbers
+    cplx* o = T + ((size_t)s * B * B + pair) * (size_t)(E + NP + 2 * n_end);
+    for (int i = threadIdx.x; i < 2 * n_end; i += 64) {
+      const int which = i >= n_end, n = i - which * n_end;
+      const cplx* tb = tab + ((size_t)s * B + (which ? bp : b)) * 3 * n_end;
+      o[E + NP + i] = cmul(tb[n], crecip(zsqrt(cmul(tb[n], tb[n_end + n]))));
+    }
     if (tree == TREE_BA) {
       for (int m = threadIdx.x; m < n2; m += 64) {          // one lane per |mu|: the degree recurrence of Pbar_n^m once
         double pmm = 0.70710678118654752440;
@@ -389,9 +397,9 @@ static bool fill_sym_entry_fits(const biem_plan* p, size_t* shm_out) {
 
 // the reduced-table form (k_fill_red): reduced pair table + phases, q factors and the chunk's transposed lists in LDS
 static bool fill_red_fits(const biem_plan* p, size_t* shm_out) {
-  const size_t shm = (size_t)(p->E + p->NP + 2 * p->n_end) * sizeof(cplx) + (size_t)p->rchunk_rows_max * 64 * 10 + 64;
+  const size_t shm = (size_t)(p->E + p->NP + 2 * p->n_end) * sizeof(cplx) + (size_t)p->rchunk_rows_max * 64 * 10 + 33 * 4 + 64;
   if (shm_out) *shm_out = shm;
-  return p->red_lists_ok && shm <= 158 * 1024 && p->E + p->NP <= 8 * 1024;
+  return p->red_lists_ok && shm <= 158 * 1024 && p->E + p->NP + 2 * p->n_end <= 8 * 1024;
 }
 
 // pair classes of the symmetric fill (k_pair_dedupe), behind the pair tables: nrep (+3 pad), rep_list[np], dup_ptr[np + 1], dup_bb[np]
@@ -401,7 +409,9 @@ constexpr int kDedupeMaxPairs = 2048;       // (the class search is quadratic in
 size_t fill_workspace_bytes(const biem_plan* p, int nb, int B) {
   // pair tables of the general / entry forms: [nb][B][B][H2 or H2lin]; of the systems-in-lanes form (needed where the entry form
   // does not fit, or when BIEM_FILL_FORM=sys forces it): [nb rounded up to 64][pairs][H2] + q factors
-  const size_t a = (size_t)nb * B * B * (p->H2lin > p->H2 ? p->H2lin : p->H2), nbp = (size_t)(nb + 63) / 64 * 64;
+  size_t row = (size_t)(p->H2lin > p->H2 ? p->H2lin : p->H2);            // general / gather forms; reduced form: T', phases, q factors
+  if ((size_t)(p->E + p->NP + 2 * p->n_end) > row) row = (size_t)(p->E + p->NP + 2 * p->n_end);
+  const size_t a = (size_t)nb * B * B * row, nbp = (size_t)(nb + 63) / 64 * 64;
   const size_t b = ((size_t)(B * (B - 1) / 2) * p->H2 + (size_t)B * p->n_end) * nbp;
   const char* form = getenv("BIEM_FILL_FORM");
   const bool need_sys = (form && form[0] == 's') || !(fill_sym_entry_fits(p, nullptr) || fill_red_fits(p, nullptr));
@@ -532,6 +542,7 @@ __global__ void __launch_bounds__(256) k_pair_dedupe(int B, int d, int npairs, c
 }
 
 constexpr int FILL_SYM_THREADS = 1024;
+constexpr int NB_TILE = 64;             // the factorisation's tile: diagonal 64 x 64 tiles are read whole
 constexpr int FILL_SYM_MAXT = 8;           // pair-table elements prefetched per thread: H2lin <= 8 * 1024
 
 // KT = pair-table elements each thread carries in registers from one combination to the next (KT * 512 >= H2); the loads are
@@ -683,21 +694,22 @@ __device__ unsigned long long g_fill_trace[8];
 #define BIEM_FT(i)
 #endif
 template <int KT>
-__global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int HR, int E, int n_end, int B, int nb, int npairs,
+__global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int HR, int E, int NP, int n_end, int B, int nb, int npairs,
                                                                 const int* __restrict__ deg, const int* __restrict__ units,
                                                                 const int* __restrict__ spos, const int* __restrict__ rchunk,
                                                                 const int* __restrict__ rcrow, const int* __restrict__ rwrow, int rows_max,
                                                                 const double* __restrict__ rcoef, const uint16_t* __restrict__ ridx,
                                                                 const uint16_t* __restrict__ rphsel,
-                                                                const cplx* __restrict__ T, const cplx* __restrict__ tab,
+                                                                const cplx* __restrict__ T,
                                                                 cplx* __restrict__ A, long long lda, long long sys_stride,
                                                                 const int* __restrict__ classes) {
   extern __shared__ char smem[];
-  cplx* sT = (cplx*)smem;                                  // [HR = E + NP] reduced pair table + phases of the current combination
-  cplx* sQ = sT + HR;                                      // [2][n_end]: q of the row ball, q of the column ball
-  double* sCoef = (double*)(sQ + 2 * n_end);               // [rows_max][64]
-  uint16_t* sIdx = (uint16_t*)(sCoef + (size_t)rows_max * 64);   // [rows_max][64]
-  __shared__ int sW[33];
+  cplx* sT = (cplx*)smem;                                  // [HR = E + NP + 2 n_end] table row of the current combination: T', phases, q factors
+  double* sCoef = (double*)(sT + HR);                      // [rows_max][64]
+  uint16_t* sIdx = (uint16_t*)(sCoef + (size_t)rows_max * 64);   // [rows_max / 4][64][4]
+  // (no static __shared__ here: statics precede the dynamic region unpadded, 33 ints would leave every ds_read_b64 / b128 below
+  // misaligned - replayed at 64 cycles per wave-instruction; measured: 143 instead of 46 ms per 256 systems of cfg 3)
+  int* sW = (int*)(sIdx + (size_t)rows_max * 64);          // [33] row offsets of the waves' lists
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p0 = rchunk[blockIdx.x], p1 = rchunk[blockIdx.x + 1], npr = p1 - p0;
@@ -708,7 +720,8 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
     for (int q = tid; q < nrows * 64; q += FILL_SYM_THREADS) { sCoef[q] = gc[q]; sIdx[q] = gi[q]; }
     if (tid < 33) sW[tid] = rwrow[blockIdx.x * 33 + tid];
   }
-  // this thread's unit pair (fixed for the whole kernel)
+  // this thread's unit pair (fixed for the whole kernel): slots, degrees, phase selectors and the offsets of its (up to) four
+  // entries inside a block, so that a combination's stores need no 64-bit multiplications
   const bool active = tid < npr;
   const int pi = p0 + (active ? tid : 0);
   const int u = pi / U, v = pi - u * U;
@@ -717,10 +730,11 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
   const int row_c = u, row_s = r2 ? U + spos[u] : 0, col_c = v, col_s = c2 ? U + spos[v] : 0;
   const int nrow = deg[rh], ncol = deg[ch];
   const unsigned selA = rphsel[2 * (size_t)pi], selB = rphsel[2 * (size_t)pi + 1];
+  const long long o00 = (long long)row_c * lda + col_c, o01 = (long long)row_c * lda + col_s, o10 = (long long)row_s * lda + col_c,
+                  o11 = (long long)row_s * lda + col_s;
   const double q2 = 0.70710678118654752440;
   const int nrep = classes[0];
-  const int* rep_list = classes + 4;
-  const int* dup_ptr = rep_list + npairs;
+  const int* dup_ptr = classes + 4 + npairs;
   const int* dup_bb = dup_ptr + npairs + 1;
   const int ncomb = nrep * nb;
 #define BIEM_TN_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
@@ -728,16 +742,10 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
   BIEM_TN_LIST(BIEM_TN_DECL)
 #define BIEM_TN_LOAD(k) if (k < KT) { const int l = k * FILL_SYM_THREADS + tid; tn##k = Tp_[l < HR ? l : HR - 1]; }
 #define BIEM_TN_PUT(k) if (k < KT) { const int l = k * FILL_SYM_THREADS + tid; if (l < HR) sT[l] = tn##k; }
-  auto pair_of = [&](int pr, int& b, int& bp) {           // pr-th upper pair (row ball b < column ball bp)
-    int bb = (int)((sqrtf(8.0f * (float)pr + 1.0f) + 1.0f) * 0.5f);
-    while (bb * (bb - 1) / 2 > pr) --bb;
-    while ((bb + 1) * bb / 2 <= pr) ++bb;
-    bp = bb; b = pr - bb * (bb - 1) / 2;
-  };
+  // a combination is (system s, class ci); its table is the one of the class's first pair (dup_bb: b << 16 | bp, the representative first)
   auto table_of = [&](int cb) -> const cplx* {
-    const int s = cb / nrep, pr = rep_list[cb - s * nrep];
-    int b, bp; pair_of(pr, b, bp);
-    return T + ((size_t)s * B * B + (size_t)b * B + bp) * HR;
+    const int s = cb / nrep, bb = dup_bb[dup_ptr[cb - s * nrep]];
+    return T + ((size_t)s * B * B + (size_t)(bb >> 16) * B + (bb & 0xffff)) * HR;
   };
   int comb = blockIdx.y;
   if (comb < ncomb) { const cplx* Tp_ = table_of(comb); BIEM_TN_LIST(BIEM_TN_LOAD) }
@@ -745,54 +753,49 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
   unsigned long long ft_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ft_t = __builtin_amdgcn_s_memtime();
 #endif
   for (; comb < ncomb; comb += gridDim.y) {
-    const int s = comb / nrep, ci = comb - s * nrep, pr = rep_list[ci];
-    int b, bp; pair_of(pr, b, bp);
+    const int s = comb / nrep, ci = comb - s * nrep;
     BIEM_FT(0)
     __syncthreads();                                       // the previous combination's readers are done (also orders the chunk loads)
     BIEM_FT(1)
     BIEM_TN_LIST(BIEM_TN_PUT)
     BIEM_FT(2)
-    if (tid < 2 * n_end) {
-      const int which = tid >= n_end, n = tid - which * n_end;
-      const cplx* tb = tab + ((size_t)s * B + (which ? bp : b)) * 3 * n_end;
-      sQ[tid] = cmul(tb[n], crecip(zsqrt(cmul(tb[n], tb[n_end + n]))));     // gj / sqrt(gj gh)
-    }
-    BIEM_FT(3)
     __syncthreads();
     BIEM_FT(4)
     if (comb + (int)gridDim.y < ncomb) { const cplx* Tp_ = table_of(comb + (int)gridDim.y); BIEM_TN_LIST(BIEM_TN_LOAD) }   // lands while this combination is contracted
     if (wave * 64 >= npr) continue;                        // (wave-uniform) no unit pair in this wave
-    const int ra = sW[2 * wave], rb = sW[2 * wave + 1], re = sW[2 * wave + 2];     // rows of list A: [ra, rb), of list B: [rb, re)
-    double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
-    {
+    // rows of list A: [ra, rb), of list B: [rb, re), all multiples of 4.  One loop over the groups of four rows, software
+    // pipelined: the coefficient / index reads of group g + 1 are in flight while the four table reads of group g are waited for
+    // (the chain index -> table entry -> fma is two dependent LDS round trips otherwise); at the A | B boundary (wave-uniform)
+    // the accumulators are handed over.
+    const int ga = sW[2 * wave] >> 2, gb = sW[2 * wave + 1] >> 2, ge = sW[2 * wave + 2] >> 2;
+    double ar = 0.0, ai = 0.0, xr = 0.0, xi = 0.0;        // running sums; (xr, xi) keeps list A's once list B has started
+    if (ga < ge) {
       const double* cc = sCoef + lane;
-      const uint16_t* ii = sIdx + lane;
-      int r = ra;
-      for (; r + 1 < rb; r += 2) {                         // two steps per trip: both coefficient / index pairs, then both table reads
-        const double c0 = cc[r * 64], c1 = cc[(r + 1) * 64];
-        const unsigned i0 = ii[r * 64], i1 = ii[(r + 1) * 64];
-        const cplx z0 = sT[i0], z1 = sT[i1];
+      const uint2* ii = (const uint2*)sIdx + lane;
+      uint2 pk = ii[(size_t)ga * 64];
+      double c0 = cc[(size_t)(4 * ga) * 64], c1 = cc[(size_t)(4 * ga + 1) * 64], c2v = cc[(size_t)(4 * ga + 2) * 64], c3 = cc[(size_t)(4 * ga + 3) * 64];
+      for (int g = ga; g < ge; ++g) {
+        const int gn = g + 1 < ge ? g + 1 : g;             // (the last trip re-reads its own group: harmless)
+        const cplx z0 = sT[pk.x & 0xffffu], z1 = sT[pk.x >> 16], z2 = sT[pk.y & 0xffffu], z3 = sT[pk.y >> 16];
+        const uint2 pkn = ii[(size_t)gn * 64];
+        const double n0 = cc[(size_t)(4 * gn) * 64], n1 = cc[(size_t)(4 * gn + 1) * 64], n2 = cc[(size_t)(4 * gn + 2) * 64], n3 = cc[(size_t)(4 * gn + 3) * 64];
+        if (g == gb) { xr = ar; xi = ai; ar = 0.0; ai = 0.0; }
         ar = fma(c0, z0.x, ar); ai = fma(c0, z0.y, ai);
         ar = fma(c1, z1.x, ar); ai = fma(c1, z1.y, ai);
+        ar = fma(c2v, z2.x, ar); ai = fma(c2v, z2.y, ai);
+        ar = fma(c3, z3.x, ar); ai = fma(c3, z3.y, ai);
+        pk = pkn; c0 = n0; c1 = n1; c2v = n2; c3 = n3;
       }
-      if (r < rb) { const double c0 = cc[r * 64]; const cplx z0 = sT[ii[r * 64]]; ar = fma(c0, z0.x, ar); ai = fma(c0, z0.y, ai); }
-      r = rb;
-      for (; r + 1 < re; r += 2) {
-        const double c0 = cc[r * 64], c1 = cc[(r + 1) * 64];
-        const unsigned i0 = ii[r * 64], i1 = ii[(r + 1) * 64];
-        const cplx z0 = sT[i0], z1 = sT[i1];
-        br = fma(c0, z0.x, br); bi = fma(c0, z0.y, bi);
-        br = fma(c1, z1.x, br); bi = fma(c1, z1.y, bi);
-      }
-      if (r < re) { const double c0 = cc[r * 64]; const cplx z0 = sT[ii[r * 64]]; br = fma(c0, z0.x, br); bi = fma(c0, z0.y, bi); }
     }
     BIEM_FT(5)
     if (!active) continue;
+    cplx RA, RB;
+    if (gb < ge) { RA = make_double2(xr, xi); RB = make_double2(ar, ai); }
+    else { RA = make_double2(ar, ai); RB = make_double2(0.0, 0.0); }
     // entries of the 2 x 2 raw block: (h,h') = phase_A R_A, its conjugate entry conj(phase_A) R_A; (h,p') = phase_B R_B, (p,h') = conj(phase_B) R_B
     cplx phA = sT[E + (selA >> 1)], phB = sT[E + (selB >> 1)];
     if (selA & 1u) phA.y = -phA.y;
     if (selB & 1u) phB.y = -phB.y;
-    const cplx RA = make_double2(ar, ai), RB = make_double2(br, bi);
     const cplx mA = cmul(RA, make_double2(phA.x, -phA.y));
     cplx x00 = cmul(RA, phA), x01 = (r2 && c2) ? cmul(RB, phB) : mA, x10 = (r2 && c2) ? cmul(RB, make_double2(phB.x, -phB.y)) : mA, x11 = mA;
     if (r2) {
@@ -805,21 +808,29 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
       const cplx a1c = make_double2((x10.x + x11.x) * q2, (x10.y + x11.y) * q2), d1 = make_double2((x11.x - x10.x) * q2, (x11.y - x10.y) * q2);
       x00 = a0c; x01 = make_double2(-d0.y, d0.x); x10 = a1c; x11 = make_double2(-d1.y, d1.x);
     }
-    const cplx scale = cmul(sQ[nrow], sQ[n_end + ncol]);
+    const cplx scale = cmul(sT[E + NP + nrow], sT[E + NP + n_end + ncol]);
+    x00 = cmul(x00, scale); x01 = cmul(x01, scale); x10 = cmul(x10, scale); x11 = cmul(x11, scale);
     cplx* As = A + (size_t)s * sys_stride;
     const int e0 = dup_ptr[ci], e1 = dup_ptr[ci + 1];
-    auto put = [&](int rslot, int cslot, cplx val) {
-      const cplx w = cmul(val, scale);
-      for (int e = e0; e < e1; ++e) {                        // every pair of the class (the representative first)
-        const int bb = dup_bb[e];
-        const int row = (bb >> 16) * H + rslot, col = (bb & 0xffff) * H + cslot;   // b < bp: strictly above the diagonal
-        As[(size_t)row * lda + col] = w;
-        if ((row >> 6) == (col >> 6)) As[(size_t)col * lda + row] = w;   // a diagonal 64 x 64 tile is read whole: mirror (A~ = A~^T)
+    for (int e = e0; e < e1; ++e) {                          // every pair of the class (the representative first)
+      const int bb = dup_bb[e];
+      const int rb0 = (bb >> 16) * H, cb0 = (bb & 0xffff) * H;     // b < bp: the block lies strictly above the diagonal
+      cplx* Ab = As + (size_t)rb0 * lda + cb0;               // (wave-uniform: scalar arithmetic)
+      Ab[o00] = x00;
+      if (c2) Ab[o01] = x01;
+      if (r2) { Ab[o10] = x10; if (c2) Ab[o11] = x11; }
+      if (cb0 - rb0 - H < NB_TILE) {
+        // a diagonal 64 x 64 tile is read whole by the factorisation: entries of this block that fall into one are mirrored (A~ = A~^T);
+        // only blocks whose first column lies within 64 of their last row can reach one
+        auto mirror = [&](int rslot, int cslot, cplx w) {
+          const int row = rb0 + rslot, col = cb0 + cslot;
+          if ((row >> 6) == (col >> 6)) As[(size_t)col * lda + row] = w;
+        };
+        mirror(row_c, col_c, x00);
+        if (c2) mirror(row_c, col_s, x01);
+        if (r2) { mirror(row_s, col_c, x10); if (c2) mirror(row_s, col_s, x11); }
       }
-    };
-    put(row_c, col_c, x00);
-    if (c2) put(row_c, col_s, x01);
-    if (r2) { put(row_s, col_c, x10); if (c2) put(row_s, col_s, x11); }
+    }
     BIEM_FT(6)
   }
 #ifdef BIEM_FILL_TRACE
@@ -1037,7 +1048,8 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
     }
     if (use_red)
       hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2, p->d_deg2, B,
-                         (const cplx*)d_k, d_centers, geom_batched, T, 0, 0, nullptr, 0, p->d_red_of, p->d_red_first, p->d_ph_mu, p->E, p->NP);
+                         (const cplx*)d_k, d_centers, geom_batched, T, 0, 0, nullptr, 0, p->d_red_of, p->d_red_first, p->d_ph_mu, p->E, p->NP,
+                         (const cplx*)d_tab, p->n_end);
     else
       hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2, p->d_deg2, B,
                          (const cplx*)d_k, d_centers, geom_batched, T, 0, 0, p->d_lin2, p->H2lin);
@@ -1061,14 +1073,14 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
     if (gy < 1) gy = 1;
     if (gy > ncomb) gy = ncomb;
     if (gy > 65535) gy = 65535;
-    const int HR = p->E + p->NP;
+    const int HR = p->E + p->NP + 2 * p->n_end;
     const int kt_need = ((use_red ? HR : p->H2lin) + FILL_SYM_THREADS - 1) / FILL_SYM_THREADS;
 #define BIEM_LAUNCH_FILL_RED(KT)                                                                                                          \
   {                                                                                                                                       \
     BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_fill_red<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                  \
-    hipLaunchKernelGGL(k_fill_red<KT>, dim3(nchunks, (unsigned)gy), dim3(FILL_SYM_THREADS), shm, st, H, U, HR, p->E, p->n_end, B, nb, npairs, \
+    hipLaunchKernelGGL(k_fill_red<KT>, dim3(nchunks, (unsigned)gy), dim3(FILL_SYM_THREADS), shm, st, H, U, HR, p->E, p->NP, p->n_end, B, nb, npairs, \
                        p->d_deg, p->d_units, p->d_spos, p->d_rchunk, p->d_rcrow, p->d_rwrow, p->rchunk_rows_max, p->d_rcoef, p->d_ridx,   \
-                       p->d_rphsel, T, (const cplx*)d_tab, (cplx*)d_A, lda, sys_stride, classes);                                        \
+                       p->d_rphsel, T, (cplx*)d_A, lda, sys_stride, classes);                                                             \
   }
     if (use_red) {
       if (kt_need <= 1) BIEM_LAUNCH_FILL_RED(1)

@@ -444,12 +444,15 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
           if (la > LA) LA = la;
           if (lb > LB) LB = lb;
         }
+        LA = (LA + 3) & ~3u; LB = (LB + 3) & ~3u;           // the kernel walks the lists in groups of four rows
         if (!rok) break;
         if ((long long)(LA + LB) > cap_rows) { rok = false; break; }                    // one wave alone exceeds the LDS budget
         if (cw == 16 || crows + LA + LB > cap_rows) close_chunk(w0);
         wr[2 * cw] = (int)crows; wr[2 * cw + 1] = (int)(crows + LA); wr[2 * cw + 2] = (int)(crows + LA + LB);
         for (int pass = 0; pass < 2; ++pass) {
           const uint32_t L = pass ? LB : LA;
+          const size_t base = p->rcoef.size();                // coefficients [row][lane]; indices [group of 4 rows][lane][4]
+          p->rcoef.resize(base + (size_t)L * 64, 0.0); p->ridx.resize(base + (size_t)L * 64, 0);
           for (uint32_t t = 0; t < L; ++t)
             for (int i = 0; i < 64; ++i) {
               double cf = 0.0; uint16_t ix = 0;
@@ -457,7 +460,8 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
                 const size_t e = pass ? eB[i] : eA[i];
                 if (t < p->ptr[e + 1] - p->ptr[e]) { cf = p->coef[p->ptr[e] + t]; ix = (uint16_t)p->red_of[p->tidx[p->ptr[e] + t]]; }
               }
-              p->rcoef.push_back(cf); p->ridx.push_back(ix);
+              p->rcoef[base + (size_t)t * 64 + i] = cf;
+              p->ridx[base + ((size_t)(t >> 2) * 64 + i) * 4 + (t & 3)] = ix;
             }
         }
         crows += LA + LB; ++cw;

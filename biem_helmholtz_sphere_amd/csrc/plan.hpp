@@ -58,7 +58,8 @@ struct biem_plan {
   std::vector<int> ph_of_unit;              // [E] phase id of the unit's first member
   // term lists per wave of 64 consecutive unit pairs, TRANSPOSED and padded to the wave's longest list: row r holds term number
   // (r - start) of the 64 lanes (coefficient 0, index 0 where a lane's list has run out), so the per-step reads of a wave are
-  // contiguous (no LDS bank conflicts).  Chunk c = unit pairs [rchunk[c], rchunk[c+1]) (at most 1024 = 16 waves), its rows
+  // contiguous (no LDS bank conflicts).  Lists are padded to multiples of 4 rows; the indices of a group of 4 rows are packed per
+  // lane (ridx[(group * 64 + lane) * 4 + k]: one 8-byte read per lane and group).  Chunk c = unit pairs [rchunk[c], rchunk[c+1]) (at most 1024 = 16 waves), its rows
   // [rcrow[c], rcrow[c+1]); rwrow[c * 33 + 2 w + {0, 1, 2}] = first row of wave w's list A, of its list B, end (relative to the chunk).
   bool red_lists_ok = false;
   std::vector<double> rcoef;                // [rows][64]
