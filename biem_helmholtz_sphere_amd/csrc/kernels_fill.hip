@@ -687,6 +687,12 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_sym(int H, int U, int
 //     step fall on (nearly) consecutive entries.
 // The gather form above measured 51 % of its LDS cycles as bank conflicts and 42 bytes of LDS per term and lane (profiles/r02_pmc_summary.txt).
 // ---------------------------------------------------------------------------------------------
+// workgroup barrier that orders LDS traffic only (see k_fill_red)
+__device__ inline void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 #ifdef BIEM_FILL_TRACE
 __device__ unsigned long long g_fill_trace[8];
 #define BIEM_FT(i) { if (tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ft_acc[i] += now_ - ft_t; ft_t = now_; } }
@@ -738,10 +744,16 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
   const int* dup_bb = dup_ptr + npairs + 1;
   const int ncomb = nrep * nb;
 #define BIEM_TN_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-#define BIEM_TN_DECL(k) cplx tn##k = make_double2(0.0, 0.0);
+  typedef double v2d_t __attribute__((ext_vector_type(2)));   // (a native vector: a struct cannot be a tied asm operand)
+#define BIEM_TN_DECL(k) v2d_t tn##k = {0.0, 0.0};
   BIEM_TN_LIST(BIEM_TN_DECL)
-#define BIEM_TN_LOAD(k) if (k < KT) { const int l = k * FILL_SYM_THREADS + tid; tn##k = Tp_[l < HR ? l : HR - 1]; }
-#define BIEM_TN_PUT(k) if (k < KT) { const int l = k * FILL_SYM_THREADS + tid; if (l < HR) sT[l] = tn##k; }
+  // The prefetch loads are inline asm and their wait is the explicit one of BIEM_TN_CLAIM: hipcc's own wait for a VGPR load is a
+  // vmcnt(0) wherever control flow joins, i.e. at the top of the loop, AFTER this combination's stores - every iteration would then
+  // wait for the acknowledgement of its own stores (microseconds under a full HBM write queue, with the CU to itself).
+#define BIEM_TN_LOAD(k) if (k < KT) { const int l = k * FILL_SYM_THREADS + tid; const cplx* a_ = Tp_ + (l < HR ? l : HR - 1); \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(tn##k) : "v"(a_) : "memory"); }
+#define BIEM_TN_CLAIM(k) if (k < KT) asm volatile("s_waitcnt vmcnt(0)" : "+v"(tn##k) : : "memory");
+#define BIEM_TN_PUT(k) if (k < KT) { const int l = k * FILL_SYM_THREADS + tid; if (l < HR) sT[l] = make_double2(tn##k.x, tn##k.y); }
   // a combination is (system s, class ci); its table is the one of the class's first pair (dup_bb: b << 16 | bp, the representative first)
   auto table_of = [&](int cb) -> const cplx* {
     const int s = cb / nrep, bb = dup_bb[dup_ptr[cb - s * nrep]];
@@ -749,25 +761,31 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
   };
   int comb = blockIdx.y;
   if (comb < ncomb) { const cplx* Tp_ = table_of(comb); BIEM_TN_LIST(BIEM_TN_LOAD) }
+  BIEM_TN_LIST(BIEM_TN_CLAIM)
 #ifdef BIEM_FILL_TRACE
   unsigned long long ft_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ft_t = __builtin_amdgcn_s_memtime();
 #endif
   for (; comb < ncomb; comb += gridDim.y) {
     const int s = comb / nrep, ci = comb - s * nrep;
     BIEM_FT(0)
-    __syncthreads();                                       // the previous combination's readers are done (also orders the chunk loads)
+    // Raw barriers with an LDS-only wait: __syncthreads() carries a workgroup-scope fence, which hipcc lowers to s_waitcnt vmcnt(0) -
+    // every barrier would wait for the acknowledgement of the previous combination's global stores (nobody in the workgroup reads
+    // them).  Only LDS traffic has to be ordered here: this wave's LDS reads / writes are complete at lgkmcnt(0).
+    lds_barrier();                                         // the previous combination's readers are done (also orders the chunk loads)
     BIEM_FT(1)
     BIEM_TN_LIST(BIEM_TN_PUT)
     BIEM_FT(2)
-    __syncthreads();
+    lds_barrier();
     BIEM_FT(4)
     if (comb + (int)gridDim.y < ncomb) { const cplx* Tp_ = table_of(comb + (int)gridDim.y); BIEM_TN_LIST(BIEM_TN_LOAD) }   // lands while this combination is contracted
-    if (wave * 64 >= npr) continue;                        // (wave-uniform) no unit pair in this wave
+    // (a wave without unit pairs runs zero groups and joins the others at the claim of the prefetched registers below: every path
+    // through the loop body must pass that point, or the compiler drains the memory queue again where the paths meet)
+    const bool wave_on = wave * 64 < npr;
     // rows of list A: [ra, rb), of list B: [rb, re), all multiples of 4.  One loop over the groups of four rows, software
     // pipelined: the coefficient / index reads of group g + 1 are in flight while the four table reads of group g are waited for
     // (the chain index -> table entry -> fma is two dependent LDS round trips otherwise); at the A | B boundary (wave-uniform)
     // the accumulators are handed over.
-    const int ga = sW[2 * wave] >> 2, gb = sW[2 * wave + 1] >> 2, ge = sW[2 * wave + 2] >> 2;
+    const int ga = wave_on ? sW[2 * wave] >> 2 : 0, gb = wave_on ? sW[2 * wave + 1] >> 2 : 0, ge = wave_on ? sW[2 * wave + 2] >> 2 : 0;
     double ar = 0.0, ai = 0.0, xr = 0.0, xi = 0.0;        // running sums; (xr, xi) keeps list A's once list B has started
     if (ga < ge) {
       const double* cc = sCoef + lane;
@@ -788,6 +806,9 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
       }
     }
     BIEM_FT(5)
+    // The prefetched table row is claimed HERE, before this combination's stores are issued: the wait then sees only the loads (issued
+    // before the contraction) and the PREVIOUS combination's stores, which have had a whole iteration to drain.
+    BIEM_TN_LIST(BIEM_TN_CLAIM)
     if (!active) continue;
     cplx RA, RB;
     if (gb < ge) { RA = make_double2(xr, xi); RB = make_double2(ar, ai); }
@@ -840,6 +861,7 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
 #undef BIEM_TN_DECL
 #undef BIEM_TN_LOAD
 #undef BIEM_TN_PUT
+#undef BIEM_TN_CLAIM
 }
 #ifdef BIEM_FILL_TRACE
 extern "C" int biem_debug_fill_trace(unsigned long long* out, int reset) {
