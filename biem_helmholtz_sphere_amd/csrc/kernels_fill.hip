@@ -781,34 +781,28 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
     // (a wave without unit pairs runs zero groups and joins the others at the claim of the prefetched registers below: every path
     // through the loop body must pass that point, or the compiler drains the memory queue again where the paths meet)
     const bool wave_on = wave * 64 < npr;
-    // Rows of list A: [4 ga, 4 gb), of list B: [4 gb, 4 ge).  One trip takes a group of four rows of EACH list - two independent
-    // chains, eight table reads in flight - and the packed indices of the next trip are read a trip ahead, so a trip costs one LDS
-    // round trip instead of two (index -> table entry -> fma).  The longest wave of a workgroup sets the time of a combination
-    // (its trips are a serial chain, the LDS bandwidth is not the limit), hence max(nA, nB) trips instead of nA + nB.  A list that
-    // has run out re-reads its last group with zero weight (all counts are wave-uniform).
+    // rows of list A: [ra, rb), of list B: [rb, re), all multiples of 4.  One loop over the groups of four rows, software
+    // pipelined: the coefficient / index reads of group g + 1 are in flight while the four table reads of group g are waited for
+    // (the chain index -> table entry -> fma is two dependent LDS round trips otherwise); at the A | B boundary (wave-uniform)
+    // the accumulators are handed over.
     const int ga = wave_on ? sW[2 * wave] >> 2 : 0, gb = wave_on ? sW[2 * wave + 1] >> 2 : 0, ge = wave_on ? sW[2 * wave + 2] >> 2 : 0;
-    const int nA = gb - ga, nB = ge - gb, ntrip = nA > nB ? nA : nB;
-    double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
-    if (ntrip > 0) {
+    double ar = 0.0, ai = 0.0, xr = 0.0, xi = 0.0;        // running sums; (xr, xi) keeps list A's once list B has started
+    if (ga < ge) {
       const double* cc = sCoef + lane;
       const uint2* ii = (const uint2*)sIdx + lane;
-      const int lastA = nA > 0 ? gb - 1 : ga, lastB = nB > 0 ? ge - 1 : ga;      // (nA == 0 or nB == 0: any valid group, weight 0)
-      uint2 pa = ii[(size_t)(nA > 0 ? ga : lastA) * 64], pb = ii[(size_t)(nB > 0 ? gb : lastB) * 64];
-      for (int t = 0; t < ntrip; ++t) {
-        const int gA = t < nA ? ga + t : lastA, gB = t < nB ? gb + t : lastB;
-        const double wA = t < nA ? 1.0 : 0.0, wB = t < nB ? 1.0 : 0.0;
-        const cplx a0 = sT[pa.x & 0xffffu], a1 = sT[pa.x >> 16], a2 = sT[pa.y & 0xffffu], a3 = sT[pa.y >> 16];
-        const cplx b0 = sT[pb.x & 0xffffu], b1 = sT[pb.x >> 16], b2 = sT[pb.y & 0xffffu], b3 = sT[pb.y >> 16];
-        const double ca0 = cc[(size_t)(4 * gA) * 64], ca1 = cc[(size_t)(4 * gA + 1) * 64], ca2 = cc[(size_t)(4 * gA + 2) * 64], ca3 = cc[(size_t)(4 * gA + 3) * 64];
-        const double cb0 = cc[(size_t)(4 * gB) * 64], cb1 = cc[(size_t)(4 * gB + 1) * 64], cb2 = cc[(size_t)(4 * gB + 2) * 64], cb3 = cc[(size_t)(4 * gB + 3) * 64];
-        const int gAn = t + 1 < nA ? gA + 1 : lastA, gBn = t + 1 < nB ? gB + 1 : lastB;
-        pa = ii[(size_t)gAn * 64]; pb = ii[(size_t)gBn * 64];
-        double sr = 0.0, si = 0.0, ur = 0.0, ui = 0.0;
-        sr = fma(ca0, a0.x, sr); si = fma(ca0, a0.y, si); ur = fma(cb0, b0.x, ur); ui = fma(cb0, b0.y, ui);
-        sr = fma(ca1, a1.x, sr); si = fma(ca1, a1.y, si); ur = fma(cb1, b1.x, ur); ui = fma(cb1, b1.y, ui);
-        sr = fma(ca2, a2.x, sr); si = fma(ca2, a2.y, si); ur = fma(cb2, b2.x, ur); ui = fma(cb2, b2.y, ui);
-        sr = fma(ca3, a3.x, sr); si = fma(ca3, a3.y, si); ur = fma(cb3, b3.x, ur); ui = fma(cb3, b3.y, ui);
-        ar = fma(wA, sr, ar); ai = fma(wA, si, ai); br = fma(wB, ur, br); bi = fma(wB, ui, bi);
+      uint2 pk = ii[(size_t)ga * 64];
+      double c0 = cc[(size_t)(4 * ga) * 64], c1 = cc[(size_t)(4 * ga + 1) * 64], c2v = cc[(size_t)(4 * ga + 2) * 64], c3 = cc[(size_t)(4 * ga + 3) * 64];
+      for (int g = ga; g < ge; ++g) {
+        const int gn = g + 1 < ge ? g + 1 : g;             // (the last trip re-reads its own group: harmless)
+        const cplx z0 = sT[pk.x & 0xffffu], z1 = sT[pk.x >> 16], z2 = sT[pk.y & 0xffffu], z3 = sT[pk.y >> 16];
+        const uint2 pkn = ii[(size_t)gn * 64];
+        const double n0 = cc[(size_t)(4 * gn) * 64], n1 = cc[(size_t)(4 * gn + 1) * 64], n2 = cc[(size_t)(4 * gn + 2) * 64], n3 = cc[(size_t)(4 * gn + 3) * 64];
+        if (g == gb) { xr = ar; xi = ai; ar = 0.0; ai = 0.0; }
+        ar = fma(c0, z0.x, ar); ai = fma(c0, z0.y, ai);
+        ar = fma(c1, z1.x, ar); ai = fma(c1, z1.y, ai);
+        ar = fma(c2v, z2.x, ar); ai = fma(c2v, z2.y, ai);
+        ar = fma(c3, z3.x, ar); ai = fma(c3, z3.y, ai);
+        pk = pkn; c0 = n0; c1 = n1; c2v = n2; c3 = n3;
       }
     }
     BIEM_FT(5)
@@ -816,7 +810,9 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
     // before the contraction) and the PREVIOUS combination's stores, which have had a whole iteration to drain.
     BIEM_TN_LIST(BIEM_TN_CLAIM)
     if (!active) continue;
-    const cplx RA = make_double2(ar, ai), RB = make_double2(br, bi);
+    cplx RA, RB;
+    if (gb < ge) { RA = make_double2(xr, xi); RB = make_double2(ar, ai); }
+    else { RA = make_double2(ar, ai); RB = make_double2(0.0, 0.0); }
     // entries of the 2 x 2 raw block: (h,h') = phase_A R_A, its conjugate entry conj(phase_A) R_A; (h,p') = phase_B R_B, (p,h') = conj(phase_B) R_B
     cplx phA = sT[E + (selA >> 1)], phB = sT[E + (selB >> 1)];
     if (selA & 1u) phA.y = -phA.y;
