@@ -125,6 +125,7 @@ int biem_plan_projection(const biem_plan* plan, double* h_W) {
 
 int biem_plan_terms(const biem_plan* plan, long long* h_ptr, double* h_coef, int* h_tidx) {
   NEED(plan, "plan");
+  if (!plan->lists_built) { set_error("biem_plan_terms: a 2-D plan of order n_end > %d holds no term lists (one Graf term per entry, evaluated directly)", kLists2dMax); return BIEM_ERR_UNSUPPORTED; }
   if (h_ptr) for (size_t i = 0; i < plan->ptr.size(); ++i) h_ptr[i] = (long long)plan->ptr[i];
   if (h_coef) memcpy(h_coef, plan->coef.data(), plan->coef.size() * sizeof(double));
   if (h_tidx) memcpy(h_tidx, plan->tidx.data(), plan->tidx.size() * sizeof(int));

@@ -89,7 +89,7 @@ int launch_harmonics(const biem_plan* p, int count, const double* d_u, double* d
 // ---------------------------------------------------------------------------------------------
 __global__ void k_ball_tables(int d, int n_end, int nb, int B, const cplx* __restrict__ k, const double* __restrict__ eta,
                               const double* __restrict__ radii, int geom_batched, const cplx* __restrict__ alpha,
-                              const cplx* __restrict__ beta, int ab_batched, cplx* __restrict__ tab) {
+                              const cplx* __restrict__ beta, int ab_batched, cplx* __restrict__ tab, cplx* __restrict__ scratch) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nb * B) return;
   int s = i / B, b = i % B;
@@ -98,7 +98,10 @@ __global__ void k_ball_tables(int d, int n_end, int nb, int B, const cplx* __res
   double rho = radii[(geom_batched ? (size_t)s * B : 0) + b];
   cplx al = alpha[(ab_batched ? (size_t)s * B : 0) + b];
   cplx be = beta[(ab_batched ? (size_t)s * B : 0) + b];
-  cplx J[kMaxRad + 3], Hh[kMaxRad + 3];
+  // orders up to kMaxRad: thread-local arrays; beyond (2-D only): 2 (n_end + 3) complex of global scratch per (system, ball)
+  cplx Jl[kMaxRad + 3], Hl[kMaxRad + 3];
+  cplx* J = scratch ? scratch + (size_t)i * 2 * (n_end + 3) : Jl;
+  cplx* Hh = scratch ? J + (n_end + 3) : Hl;
   const cplx x = cscale(kk, rho);
   radial_jh(d, n_end, x, J, Hh);   // orders 0..n_end (one extra for the derivative); Im k = 0 takes the real routines
   const cplx ix = crecip(x);
@@ -125,13 +128,16 @@ __global__ void k_ball_tables(int d, int n_end, int nb, int B, const cplx* __res
 
 int launch_ball_tables(const biem_plan* p, int nb, int B, const double* d_k, const double* d_eta, const double* d_radii,
                        int geom_batched, const double* d_alpha, const double* d_beta, int ab_batched, double* d_tab, hipStream_t st) {
-  if (p->n_end > kMaxRad) { set_error("n_end=%d exceeds the built table size %d", p->n_end, kMaxRad); return BIEM_ERR_UNSUPPORTED; }
+  if (p->n_end > kMaxRad && p->tree != TREE_A) { set_error("n_end=%d exceeds the built table size %d", p->n_end, kMaxRad); return BIEM_ERR_UNSUPPORTED; }
   int total = nb * B;
   if (total <= 0) return BIEM_OK;
   ProfScope ps(PK_TABLES, st);
+  cplx* scratch = nullptr;
+  if (p->n_end > kMaxRad) BIEM_HIPCHK(hipMallocAsync((void**)&scratch, (size_t)total * 2 * (p->n_end + 3) * sizeof(cplx), st));   // (2-D, large orders: stream-ordered)
   hipLaunchKernelGGL(k_ball_tables, dim3((total + 63) / 64), dim3(64), 0, st, p->d, p->n_end, nb, B, (const cplx*)d_k, d_eta, d_radii,
-                     geom_batched, (const cplx*)d_alpha, (const cplx*)d_beta, ab_batched, (cplx*)d_tab);
+                     geom_batched, (const cplx*)d_alpha, (const cplx*)d_beta, ab_batched, (cplx*)d_tab, scratch);
   BIEM_LAUNCHCHK();
+  if (scratch) BIEM_HIPCHK(hipFreeAsync(scratch, st));
   return BIEM_OK;
 }
 
@@ -148,10 +154,14 @@ __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int
                                                      int lower, int nbp, const int* __restrict__ lin2, int H2lin,
                                                      const int* __restrict__ red_of = nullptr, const int* __restrict__ red_first = nullptr,
                                                      const int* __restrict__ ph_mu = nullptr, int E = 0, int NP = 0,
-                                                     const cplx* __restrict__ tab = nullptr, int n_end = 0) {
-  __shared__ cplx sJ[kMaxRad * 2 + 6];
-  __shared__ cplx sH[kMaxRad * 2 + 6];
+                                                     const cplx* __restrict__ tab = nullptr, int n_end = 0, cplx* __restrict__ rad_scratch = nullptr) {
+  __shared__ cplx sJl[kMaxRad * 2 + 6];
+  __shared__ cplx sHl[kMaxRad * 2 + 6];
   int pair = blockIdx.x, s = blockIdx.y;
+  // radial functions of the pair: LDS up to order 2 kMaxRad; beyond (2-D only) 2 (n2 + 6) complex of global scratch per block (written by
+  // thread 0, read by the block after the barrier: same CU, fresh addresses)
+  cplx* sJ = rad_scratch ? rad_scratch + ((size_t)s * gridDim.x + pair) * 2 * (n2 + 6) : sJl;
+  cplx* sH = rad_scratch ? sJ + (n2 + 6) : sHl;
   int b = pair / B, bp = pair % B;
   // both fills contract the blocks b < bp (the general fill derives block (bp, b) from (b, bp) by the parity sign, the symmetric
   // fill writes the upper triangle only); lower = 1 (tables of the pairs b > bp instead) is kept for tests
@@ -418,6 +428,31 @@ size_t fill_workspace_bytes(const biem_plan* p, int nb, int B) {
   return (need_sys && b > a ? b : a) * sizeof(cplx) + fill_dedupe_bytes(B);
 }
 
+__global__ void k_fill2d(int n_end, int H, int B, int npairs, const cplx* __restrict__ T, const cplx* __restrict__ tab, int scaling,
+                         cplx* __restrict__ A, long long lda, long long sys_stride);        // (defined with the 2-D fills below)
+// k_pair_tables in reduced mode (table rows T' | phases | q factors); 2-D orders whose radial arrays exceed the kernel's LDS take
+// stream-ordered global scratch
+static int launch_pair_tables_red(const biem_plan* p, int nb, int B, const double* d_k, const double* d_centers, int geom_batched,
+                                  const double* d_tab, cplx* T, hipStream_t st) {
+  cplx* scratch = nullptr;
+  if (p->n2 + 6 > kMaxRad * 2 + 6) {
+    if (p->tree != TREE_A) { set_error("n_end=%d exceeds the built table size", p->n_end); return BIEM_ERR_UNSUPPORTED; }
+    BIEM_HIPCHK(hipMallocAsync((void**)&scratch, (size_t)nb * B * B * 2 * (p->n2 + 6) * sizeof(cplx), st));
+  }
+  hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2, p->d_deg2, B,
+                     (const cplx*)d_k, d_centers, geom_batched, T, 0, 0, nullptr, 0, p->d_red_of, p->d_red_first, p->d_ph_mu, p->E, p->NP,
+                     (const cplx*)d_tab, p->n_end, scratch);
+  BIEM_LAUNCHCHK();
+  if (scratch) BIEM_HIPCHK(hipFreeAsync(scratch, st));
+  return BIEM_OK;
+}
+// the list-free 2-D kernels index the table row directly: T'[j] at j, phase e^{i j phi} at E + j (phase ids in order of the orders)
+static bool plan_2d_direct(const biem_plan* p) {
+  if (p->tree != TREE_A || p->E != p->n2 || p->NP != p->n2 || (int)p->ph_mu.size() != 2 * p->n2) return false;
+  for (int i = 0; i < p->n2; ++i) if (p->ph_mu[2 * i] != i || p->red_label[i] != i) return false;
+  return true;
+}
+
 int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const double* d_centers, int geom_batched,
                 const double* d_tab, int scaling, double* d_A, long long lda, long long sys_stride, int n_pad,
                 void* d_work, size_t work_bytes, hipStream_t st) {
@@ -425,10 +460,26 @@ int launch_fill(const biem_plan* p, int nb, int B, const double* d_k, const doub
   if (nb <= 0 || B <= 0) return BIEM_OK;
   if (lda < (n_pad > N ? n_pad : N) || n_pad < N) { set_error("biem_fill: lda/n_pad too small"); return BIEM_ERR_ARG; }
   if (work_bytes < fill_workspace_bytes(p, nb, B)) { set_error("biem_fill: workspace too small"); return BIEM_ERR_ARG; }
-  if (2 * p->n_end > kMaxRad) { set_error("n_end=%d exceeds the built table size", p->n_end); return BIEM_ERR_UNSUPPORTED; }
   if (scaling != BIEM_FILL_REFERENCE && scaling != BIEM_FILL_EQUILIBRATED) { set_error("biem_fill: bad scaling"); return BIEM_ERR_ARG; }
   cplx* T = (cplx*)d_work;
   ProfScope ps(PK_FILL, st, 16.0 * (double)nb * N * (double)N);
+  if (p->tree == TREE_A && (!p->lists_built || !getenv("BIEM_FILL_FORM"))) {
+    // 2-D: no term lists, any order (BIEM_FILL_FORM set: the generic list kernel below, for A / B tests)
+    if (!plan_2d_direct(p)) { set_error("biem_fill: internal: 2-D table order"); return BIEM_ERR_ARG; }
+    if (nb > 65535) { set_error("biem_fill: at most 65535 systems per call"); return BIEM_ERR_ARG; }
+    const int npairs = B * (B - 1) / 2;
+    if (npairs + B > 65535) { set_error("biem_fill (2-D): too many balls for one launch (%d)", B); return BIEM_ERR_UNSUPPORTED; }
+    if (B > 1) { const int rc = launch_pair_tables_red(p, nb, B, d_k, d_centers, geom_batched, d_tab, T, st); if (rc) return rc; }
+    hipLaunchKernelGGL(k_fill2d, dim3((unsigned)(((long long)H * H + 255) / 256), npairs + B, nb), dim3(256), 0, st, p->n_end, H, B, npairs, T,
+                       (const cplx*)d_tab, scaling, (cplx*)d_A, lda, sys_stride);
+    BIEM_LAUNCHCHK();
+    if (n_pad > N) {
+      hipLaunchKernelGGL(k_fill_pad, dim3(64, nb), dim3(256), 0, st, N, n_pad, (cplx*)d_A, lda, sys_stride);
+      BIEM_LAUNCHCHK();
+    }
+    return BIEM_OK;
+  }
+  if (2 * p->n_end > kMaxRad) { set_error("n_end=%d exceeds the built table size", p->n_end); return BIEM_ERR_UNSUPPORTED; }
   if (B > 1) {
     hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2,
                        p->d_deg2, B, (const cplx*)d_k, d_centers, geom_batched, T, 0, 0, nullptr, 0);
@@ -872,6 +923,120 @@ extern "C" int biem_debug_fill_trace(unsigned long long* out, int reset) {
 #endif
 
 // ---------------------------------------------------------------------------------------------
+// 2-D fills without term lists (tree a, any order).  Graf's theorem leaves ONE term per entry,
+//     S(m, m') = i^{|m| + |mu| - |m'|} T[mu],   mu = m' - m,   T[mu] = T'[|mu|] e^{i mu phi},   T'[j] = C_2 H_j(k|t|) / (2 pi),
+// so a block is a Toeplitz matrix in (m, m') up to signs: every thread evaluates its entries from the table row of the pair
+// (k_pair_tables in reduced mode: T'[0 .. 2 n_end - 2], the phases e^{i j phi}, j >= 0, and the q factors of the two balls) read
+// straight from global memory - consecutive lanes read consecutive entries, the row (at most 6 n_end complex numbers) stays in L1 /
+// L2 - and stores them.  No LDS, no term lists: the plan of a 2-D order beyond kLists2dMax holds none (they would be H^2 = 47 M
+// one-term entries at the reference's n_end = 3444, accuracy/accuracy_k_a.csv), and the kernels are bound by their stores.
+// ---------------------------------------------------------------------------------------------
+__device__ inline double sign_even(int e) { return ((e / 2) & 1) ? -1.0 : 1.0; }      // i^e for even e (either sign)
+
+// symmetric form: one thread per unit pair (m, m'), 0 <= m, m' < n_end, of the block (b, bp), b < bp; grid (unit pairs / 256, combinations)
+__global__ void __launch_bounds__(256) k_fill2d_sym(int n_end, int H, int B, int nb, int npairs, const cplx* __restrict__ T, cplx* __restrict__ A,
+                                                     long long lda, long long sys_stride, const int* __restrict__ classes) {
+  const int E = 2 * n_end - 1, HR = 2 * E + 2 * n_end, U = n_end;
+  const int pi = blockIdx.x * 256 + threadIdx.x;
+  if (pi >= U * U) return;
+  const int m = pi / U, mp = pi - m * U;
+  const bool r2 = m > 0, c2 = mp > 0;
+  // slots of a ball's unknowns: cosine combination of unit m at m, its sine combination at U + m - 1
+  const int row_c = m, row_s = U + m - 1, col_c = mp, col_s = U + mp - 1;
+  const long long o00 = (long long)row_c * lda + col_c, o01 = (long long)row_c * lda + col_s, o10 = (long long)row_s * lda + col_c,
+                  o11 = (long long)row_s * lda + col_s;
+  const int muA = mp - m, jA = muA < 0 ? -muA : muA, jB = m + mp;
+  const double sA = muA >= 0 ? 1.0 : ((jA & 1) ? -1.0 : 1.0);       // i^{m + |mu| - m'}: 1 for m' >= m, (-1)^{m - m'} otherwise
+  const double sB = (m & 1) ? -1.0 : 1.0;                            // (h, p'): mu = -(m + m'), i^{2 m}
+  const double q2 = 0.70710678118654752440;
+  const int nrep = classes[0];
+  const int* dup_ptr = classes + 4 + npairs;
+  const int* dup_bb = dup_ptr + npairs + 1;
+  const int ncomb = nrep * nb;
+  for (int comb = blockIdx.y; comb < ncomb; comb += gridDim.y) {
+    const int s = comb / nrep, ci = comb - s * nrep;
+    const int e0 = dup_ptr[ci], e1 = dup_ptr[ci + 1], bb0 = dup_bb[e0];
+    const cplx* row = T + ((size_t)s * B * B + (size_t)(bb0 >> 16) * B + (bb0 & 0xffff)) * HR;
+    const cplx tA = row[jA], tB = row[jB];
+    cplx phA = row[E + jA], phB = row[E + jB];
+    const cplx scale = cmul(row[2 * E + m], row[2 * E + n_end + mp]);
+    if (muA < 0) phA.y = -phA.y;                          // T[mu] = T'[|mu|] e^{i mu phi}
+    const cplx RA = cscale(tA, sA), RB = cscale(tB, sB);
+    // raw 2 x 2 block of the units (m, -m) x (m', -m'): (h,h') = R_A e^{i mu_A phi}, (p,p') its conjugate-phase partner,
+    // (h,p') = R_B e^{-i (m + m') phi}, (p,h') = R_B e^{+i (m + m') phi}
+    const cplx mA = cmul(RA, make_double2(phA.x, -phA.y));
+    cplx x00 = cmul(RA, phA), x01 = (r2 && c2) ? cmul(RB, make_double2(phB.x, -phB.y)) : mA, x10 = (r2 && c2) ? cmul(RB, phB) : mA, x11 = mA;
+    if (r2) {
+      const cplx a0c = make_double2((x00.x + x10.x) * q2, (x00.y + x10.y) * q2), a1c = make_double2((x01.x + x11.x) * q2, (x01.y + x11.y) * q2);
+      const cplx d0 = make_double2((x00.x - x10.x) * q2, (x00.y - x10.y) * q2), d1 = make_double2((x01.x - x11.x) * q2, (x01.y - x11.y) * q2);
+      x00 = a0c; x01 = a1c; x10 = make_double2(-d0.y, d0.x); x11 = make_double2(-d1.y, d1.x);
+    }
+    if (c2) {
+      const cplx a0c = make_double2((x00.x + x01.x) * q2, (x00.y + x01.y) * q2), d0 = make_double2((x01.x - x00.x) * q2, (x01.y - x00.y) * q2);
+      const cplx a1c = make_double2((x10.x + x11.x) * q2, (x10.y + x11.y) * q2), d1 = make_double2((x11.x - x10.x) * q2, (x11.y - x10.y) * q2);
+      x00 = a0c; x01 = make_double2(-d0.y, d0.x); x10 = a1c; x11 = make_double2(-d1.y, d1.x);
+    }
+    x00 = cmul(x00, scale); x01 = cmul(x01, scale); x10 = cmul(x10, scale); x11 = cmul(x11, scale);
+    cplx* As = A + (size_t)s * sys_stride;
+    for (int e = e0; e < e1; ++e) {                          // every pair of the class (the representative first)
+      const int bb = dup_bb[e];
+      const int rb0 = (bb >> 16) * H, cb0 = (bb & 0xffff) * H;
+      cplx* Ab = As + (size_t)rb0 * lda + cb0;
+      Ab[o00] = x00;
+      if (c2) Ab[o01] = x01;
+      if (r2) { Ab[o10] = x10; if (c2) Ab[o11] = x11; }
+      if (cb0 - rb0 - H < NB_TILE) {                         // entries inside a diagonal 64 x 64 tile are mirrored (read whole)
+        auto mirror = [&](int rslot, int cslot, cplx w) {
+          const int rr = rb0 + rslot, cc = cb0 + cslot;
+          if ((rr >> 6) == (cc >> 6)) As[(size_t)cc * lda + rr] = w;
+        };
+        mirror(row_c, col_c, x00);
+        if (c2) mirror(row_c, col_s, x01);
+        if (r2) { mirror(row_s, col_c, x10); if (c2) mirror(row_s, col_s, x11); }
+      }
+    }
+  }
+}
+
+// general form (reference / equilibrated scaling, natural order of the harmonics: m = 0 .. n-1, -(n-1) .. -1): one thread per entry
+// (h, h') of the pair (b, bp), b < bp, writes block (b, bp) and - through T(-t) = (-1)^{n''} T(t) - block (bp, b); blockIdx.y >=
+// npairs: the diagonal block of ball blockIdx.y - npairs.
+__global__ void __launch_bounds__(256) k_fill2d(int n_end, int H, int B, int npairs, const cplx* __restrict__ T, const cplx* __restrict__ tab,
+                                                 int scaling, cplx* __restrict__ A, long long lda, long long sys_stride) {
+  const int E = 2 * n_end - 1, HR = 2 * E + 2 * n_end;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)H * H) return;
+  const int h = (int)(e / H), hp = (int)(e - (long long)h * H);
+  const int s = blockIdx.z;
+  cplx* As = A + (size_t)s * sys_stride;
+  if ((int)blockIdx.y >= npairs) {
+    const int b = blockIdx.y - npairs;
+    const int n = h < n_end ? h : H - h;
+    const cplx* tb = tab + ((size_t)s * B + b) * 3 * n_end;
+    cplx v = make_double2(0.0, 0.0);
+    if (h == hp) v = scaling == BIEM_FILL_REFERENCE ? cmul(tb[n_end + n], tb[2 * n_end + n]) : make_double2(1.0, 0.0);
+    As[((size_t)b * H + h) * lda + (size_t)b * H + hp] = v;
+    return;
+  }
+  int bp = (int)((sqrtf(8.0f * (float)blockIdx.y + 1.0f) + 1.0f) * 0.5f);
+  while (bp * (bp - 1) / 2 > (int)blockIdx.y) --bp;
+  while ((bp + 1) * bp / 2 <= (int)blockIdx.y) ++bp;
+  const int b = blockIdx.y - bp * (bp - 1) / 2;
+  const int m = h < n_end ? h : h - H, mp = hp < n_end ? hp : hp - H;          // signed orders
+  const int am = m < 0 ? -m : m, amp = mp < 0 ? -mp : mp, mu = mp - m, j = mu < 0 ? -mu : mu;
+  const cplx* row = T + ((size_t)s * B * B + (size_t)b * B + bp) * HR;
+  cplx ph = row[E + j];
+  if (mu < 0) ph.y = -ph.y;
+  const cplx raw = cscale(cmul(row[j], ph), sign_even(am + j - amp));
+  const cplx* tb = tab + ((size_t)s * B + b) * 3 * n_end;
+  const cplx* tbp = tab + ((size_t)s * B + bp) * 3 * n_end;
+  auto colfac = [&](const cplx* tball, int n) { return scaling == BIEM_FILL_REFERENCE ? tball[2 * n_end + n] : crecip(tball[n_end + n]); };
+  As[((size_t)b * H + h) * lda + (size_t)bp * H + hp] = cmul(cmul(raw, tb[am]), colfac(tbp, amp));
+  const cplx mm = cmul(cmul(raw, tbp[am]), colfac(tb, amp));
+  As[((size_t)bp * H + h) * lda + (size_t)b * H + hp] = ((am + amp) & 1) ? make_double2(-mm.x, -mm.y) : mm;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Symmetric fill, systems in lanes (batches of >= 32 systems): lane = system, the wave walks the unit pairs of its chunk one
 // after the other.  Every lane of a wave then runs the SAME term list: the coefficient and the table index of a term are
 // wave-uniform (broadcast LDS reads), the pair-table row T[l][0..63] of the 64 systems is one contiguous 1-KiB load (tables
@@ -1020,10 +1185,30 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
   if (nb <= 0 || B <= 0) return BIEM_OK;
   if (lda < n_pad || n_pad < N || n_pad % 64) { set_error("biem_fill (symmetric): lda / n_pad too small or n_pad not a multiple of 64"); return BIEM_ERR_ARG; }
   if (work_bytes < fill_workspace_bytes(p, nb, B)) { set_error("biem_fill: workspace too small"); return BIEM_ERR_ARG; }
-  if (2 * p->n_end > kMaxRad) { set_error("n_end=%d exceeds the built table size", p->n_end); return BIEM_ERR_UNSUPPORTED; }
   if (nb > 65535) { set_error("biem_fill (symmetric): at most 65535 systems per call"); return BIEM_ERR_ARG; }
   cplx* T = (cplx*)d_work;
   ProfScope ps(PK_FILL, st, (double)nb * fill_sym_bytes(n_pad));
+  const bool direct2d = p->tree == TREE_A && (!p->lists_built || !getenv("BIEM_FILL_FORM"));
+  if (!direct2d && 2 * p->n_end > kMaxRad) { set_error("n_end=%d exceeds the built table size", p->n_end); return BIEM_ERR_UNSUPPORTED; }
+  if (direct2d && B > 1) {
+    // 2-D: the list-free kernel (any order); pair classes as in the list forms
+    if (!plan_2d_direct(p)) { set_error("biem_fill (symmetric): internal: 2-D table order"); return BIEM_ERR_ARG; }
+    { const int rc = launch_pair_tables_red(p, nb, B, d_k, d_centers, geom_batched, d_tab, T, st); if (rc) return rc; }
+    const int npairs = B * (B - 1) / 2;
+    int* classes = (int*)((char*)d_work + fill_workspace_bytes(p, nb, B) - fill_dedupe_bytes(B));
+    const char* mn = getenv("BIEM_FILL_DEDUPE_MIN");
+    const bool on = dedupe && !geom_batched && nb >= (mn ? atoi(mn) : 8) && npairs <= kDedupeMaxPairs && B <= 65535 && !getenv("BIEM_FILL_NO_DEDUPE");
+    const size_t shm_dd = on ? (size_t)(B + 3 * npairs + 2) * sizeof(int) + (size_t)npairs * p->d * sizeof(double) : 0;
+    if (shm_dd > 48 * 1024) BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_pair_dedupe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_dd));
+    hipLaunchKernelGGL(k_pair_dedupe, dim3(1), dim3(256), shm_dd, st, B, p->d, npairs, d_centers,
+                       on ? dedupe->radii : nullptr, on ? dedupe->alpha : nullptr, on ? dedupe->beta : nullptr, on ? 1 : 0, classes);
+    BIEM_LAUNCHCHK();
+    const long long ncomb = (long long)npairs * nb;
+    const unsigned gx = (unsigned)(((long long)U * U + 255) / 256);
+    long long gy = ncomb < 65535 ? ncomb : 65535;
+    hipLaunchKernelGGL(k_fill2d_sym, dim3(gx, (unsigned)gy), dim3(256), 0, st, p->n_end, H, B, nb, npairs, T, (cplx*)d_A, lda, sys_stride, classes);
+    BIEM_LAUNCHCHK();
+  }
   // Two forms.  "entry" (one unit pair per lane, pair table in LDS) is the fast one wherever its tables fit LDS; "sys" (one
   // system per lane, pair tables from L2 / Infinity Cache: bound by the ~35-70 GB/s a CU gets from there, 150 vs 92 ms per 256
   // systems at cfg 3) has no ceiling on the order and takes over where the entry form does not fit.  BIEM_FILL_FORM forces one.
@@ -1035,7 +1220,7 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
   const bool use_red = red_fits && !(form && (form[0] == 's' || form[0] == 'e'));
   const bool entry_fits = use_red || fill_sym_entry_fits(p, &shm_entry);
   const bool sys_form = form ? (form[0] == 's') : !entry_fits;
-  if (B > 1 && sys_form) {
+  if (!direct2d && B > 1 && sys_form) {
     // systems in lanes.  Workspace: Tt[groups][npairs][H2][64] then Qt[groups][B][n_end][64] (fill_workspace_bytes covers it)
     const int nbp = (nb + 63) / 64 * 64, npairs = B * (B - 1) / 2;
     const size_t need = ((size_t)npairs * p->H2 + (size_t)B * p->n_end) * nbp * sizeof(cplx);
@@ -1061,7 +1246,7 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
                        p->d_units, p->d_spos, p->d_schunk, p->schunk_terms_max, p->schunk_pairs_max, p->d_qptr, p->d_qcoef, p->d_qidx16,
                        (const cplx*)T, (const cplx*)Qt, (cplx*)d_A, lda, sys_stride, getenv("BIEM_ABL_FILL_NOSTORE") ? 1 : 0);
     BIEM_LAUNCHCHK();
-  } else if (B > 1) {
+  } else if (!direct2d && B > 1) {
     const int nchunks = use_red ? (int)p->rchunk.size() - 1 : (int)p->qchunk.size() - 1;
     const size_t shm = use_red ? shm_red : shm_entry;
     if (!entry_fits) {

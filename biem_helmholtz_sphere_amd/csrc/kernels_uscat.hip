@@ -19,10 +19,14 @@ constexpr int kMaxRadU = 320;
 __global__ void __launch_bounds__(64) k_uscat_coef(int d, int H, int n_end, const int* __restrict__ deg, int B, int inner,
                                                     const cplx* __restrict__ k, const double* __restrict__ eta,
                                                     const double* __restrict__ radii, int geom_batched,
-                                                    const cplx* __restrict__ dens, cplx* __restrict__ c) {
-  __shared__ cplx sJ[kMaxRadU + 3], sH[kMaxRadU + 3];
-  __shared__ cplx sB[kMaxRadU];
+                                                    const cplx* __restrict__ dens, cplx* __restrict__ c, cplx* __restrict__ scratch) {
+  __shared__ cplx sJl[kMaxRadU + 3], sHl[kMaxRadU + 3];
+  __shared__ cplx sBl[kMaxRadU];
   int b = blockIdx.x, s = blockIdx.y;
+  // orders beyond kMaxRadU (2-D only): 3 (n_end + 3) complex of global scratch per block (written by thread 0, read after the barrier)
+  cplx* sJ = scratch ? scratch + ((size_t)s * gridDim.x + b) * 3 * (n_end + 3) : sJl;
+  cplx* sH = scratch ? sJ + (n_end + 3) : sHl;
+  cplx* sB = scratch ? sH + (n_end + 3) : sBl;
   const cplx kk = k[s];
   const double et = eta[s];
   double rho = radii[(geom_batched ? (size_t)s * B : 0) + b];
@@ -352,19 +356,27 @@ int launch_uscat(const biem_plan* p, int nb, int B, int P, const double* d_k, co
                  const double* d_radii, int geom_batched, const double* d_density, const double* d_points, int flags,
                  double* d_out, void* d_work, size_t work_bytes, hipStream_t st) {
   if (nb <= 0 || B <= 0 || P <= 0) return BIEM_OK;
-  if (p->n_end > kMaxRadU) { set_error("biem_uscat: n_end too large"); return BIEM_ERR_UNSUPPORTED; }
+  // orders beyond the LDS tables: 2-D only, through the per-lane kernel (its only table is the ball's 2 n_end - 1 coefficients)
+  const bool big = p->n_end > kMaxRadU;
+  if (big && (p->tree != TREE_A || (size_t)(2 * p->n_end - 1) * sizeof(cplx) > 150 * 1024 ||
+              ((flags & BIEM_USCAT_KIND_INNER) && !(flags & BIEM_USCAT_FAR_FIELD)) || nb > 65535)) {
+    set_error("biem_uscat: n_end=%d too large for this tree / kind", p->n_end); return BIEM_ERR_UNSUPPORTED;
+  }
   size_t need = (size_t)nb * B * p->H * sizeof(cplx);
   if (work_bytes < need) { set_error("biem_uscat: workspace too small"); return BIEM_ERR_ARG; }
   cplx* c = (cplx*)d_work;
+  cplx* scratch = nullptr;
+  if (big) BIEM_HIPCHK(hipMallocAsync((void**)&scratch, (size_t)nb * B * 3 * (p->n_end + 3) * sizeof(cplx), st));
   hipLaunchKernelGGL(k_uscat_coef, dim3(B, nb), dim3(64), 0, st, p->d, p->H, p->n_end, p->d_deg, B,
                      (flags & BIEM_USCAT_KIND_INNER) && !(flags & BIEM_USCAT_FAR_FIELD) ? 1 : 0, (const cplx*)d_k, d_eta, d_radii,
-                     geom_batched, (const cplx*)d_density, c);
+                     geom_batched, (const cplx*)d_density, c, scratch);
   BIEM_LAUNCHCHK();
+  if (scratch) BIEM_HIPCHK(hipFreeAsync(scratch, st));
   // (the far field does not depend on the kind; the near field of kind inner needs j_n: the generic kernel)
   const bool far = (flags & BIEM_USCAT_FAR_FIELD) != 0;
   const bool fast_ok = far || !(flags & BIEM_USCAT_KIND_INNER);
   if (fast_ok && !getenv("BIEM_USCAT_GENERIC") && nb <= 65535 &&
-      ((p->tree == TREE_BA && p->n_end <= kFastNendMax3) || (p->tree == TREE_A && p->n_end <= kFastNendMax2) ||
+      ((p->tree == TREE_BA && p->n_end <= kFastNendMax3) || (p->tree == TREE_A && (big || p->n_end <= kFastNendMax2)) ||
        (p->tree == TREE_BBA && p->n_end <= kFastNendMax4))) {
     const int ne = p->n_end;
     if (p->tree == TREE_BA) {

@@ -178,9 +178,14 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
     }
   }
   // ---- translation terms ----
-  p->ptr.assign((size_t)H * H + 1, 0);
+  // 2-D beyond kLists2dMax: no term lists at all (H^2 entries of one term each: 1.4 GB at the reference's n_end = 3444) - the 2-D
+  // fills evaluate S(m, m') = i^{|m| + |mu| - |m'|} T[mu], mu = m' - m, directly (k_fill2d_sym / k_fill2d, any order)
+  const bool lists = !(tree == TREE_A && n_end > kLists2dMax);
+  p->lists_built = lists;
+  p->ptr.assign(lists ? (size_t)H * H + 1 : 1, 0);
   p->coef.clear(); p->tidx.clear();
-  if (tree == TREE_A) {
+  if (!lists) {
+  } else if (tree == TREE_A) {
     const int n2 = p->n2;
     for (int h = 0; h < H; ++h) for (int hp = 0; hp < H; ++hp) {
       int m = p->labels[3 * h], mp = p->labels[3 * hp], mu = mp - m;
@@ -262,6 +267,9 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
           const double* c = &Ab[((size_t)q2 * n2 + l2) * nq];
           double a4 = 0.0;
           for (int qd = 0; qd < nq; ++qd) a4 += wc[qd] * a[qd] * b[qd] * c[qd];
+          // (quadrature noise of a polar integral that vanishes by a selection rule reaches 3e-14 at n_end = 15; integrals that do not
+          // vanish are >= 1e-9 there: oracle/biem_oracle.py::_theta4)
+          if (fabs(a4) < 1e-12) continue;
           double v = a4 * g3;
           if (fabs(v) < 1e-14) continue;   // vanishes by a selection rule; only quadrature rounding is left
           p->coef.push_back(isign_even(q + q2 - qp) * v);
@@ -288,7 +296,7 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
     p->chunk_ent.push_back(0);
     p->chunk_terms_max = 0; p->chunk_ents_max = 0;
     long long e0 = 0;
-    while (e0 < total) {
+    while (lists && e0 < total) {
       long long e1 = e0 + 1;
       while (e1 < total && e1 - e0 < max_ents && (long long)(p->ptr[e1 + 1] - p->ptr[e0]) <= cap_terms) ++e1;
       int nt = (int)(p->ptr[e1] - p->ptr[e0]);
@@ -308,10 +316,10 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
       p->hpos[h] = u;
       if (pp != h) { p->spos[u] = ns; p->hpos[pp] = U + ns; ++ns; }
     }
-    p->qptr.assign((size_t)4 * U * U + 1, 0);
+    p->qptr.assign(lists ? (size_t)4 * U * U + 1 : 1, 0);
     p->qcoef.clear(); p->qidx16.clear();
     p->qcoef.reserve(p->coef.size()); p->qidx16.reserve(p->coef.size());
-    for (int u = 0; u < U; ++u)
+    for (int u = 0; u < (lists ? U : 0); ++u)
       for (int v = 0; v < U; ++v) {
         const int hh[2] = {p->units[2 * u], p->units[2 * u + 1]}, cc[2] = {p->units[2 * v], p->units[2 * v + 1]};
         for (int slot = 0; slot < 4; ++slot) {
@@ -343,8 +351,9 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
         if (l <= partner2[l]) { p->lin2[l] = 2 * ne; if (partner2[l] != l) p->lin2[partner2[l]] = 2 * ne + 1; ++ne; }
       p->H2lin = 2 * ne;
       if (p->H2lin > 65535) ok = false;
-      p->q2ptr.assign((size_t)2 * U * U + 1, 0);
+      p->q2ptr.assign(lists ? (size_t)2 * U * U + 1 : 1, 0);
       p->q2coef.clear(); p->q2idx16.clear();
+      const int Ul = lists ? U : 0;            // (no lists: the loops over unit pairs below do nothing)
       auto same_mirrored = [&](size_t ea, size_t eb) {      // list of entry eb == list of entry ea with partner indices?
         if (p->ptr[ea + 1] - p->ptr[ea] != p->ptr[eb + 1] - p->ptr[eb]) return false;
         for (uint32_t q = p->ptr[ea], r = p->ptr[eb]; q < p->ptr[ea + 1]; ++q, ++r) {
@@ -353,7 +362,7 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
         }
         return true;
       };
-      for (int u = 0; u < U && ok; ++u)
+      for (int u = 0; u < Ul && ok; ++u)
         for (int v = 0; v < U && ok; ++v) {
           const int h = p->units[2 * u], pp = p->units[2 * u + 1], ch = p->units[2 * v], cp = p->units[2 * v + 1];
           const bool r2 = pp != h, c2 = cp != ch;
@@ -371,7 +380,7 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
           }
           p->q2ptr[((size_t)u * U + v) * 2 + 2] = (uint32_t)p->q2coef.size();
         }
-      p->pair_lists_ok = ok;
+      p->pair_lists_ok = ok && lists;
       // ---- reduced-table form: T'[e] shared by a label and its partner, one phase per list (plan.hpp) ----
       bool rok = ok;
       p->E = ne; p->red_of.assign(H2, 0); p->red_first.assign(H2, 0); p->red_label.assign(ne, 0);
@@ -397,7 +406,7 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
       p->NP = (int)phid.size();
       if (p->E + p->NP > 65535 || p->NP > 32767) rok = false;
       // per list: all terms of one kind (first members / partners / self-conjugate) and of one phase id
-      p->rphsel.assign((size_t)2 * U * U, 0);
+      p->rphsel.assign(lists ? (size_t)2 * U * U : 0, 0);
       auto list_sel = [&](size_t e, uint16_t& sel) {     // phase selector of entry e's list; false if the list is not uniform
         int kind = -1, id = -1;
         for (uint32_t q = p->ptr[e]; q < p->ptr[e + 1]; ++q) {
@@ -415,7 +424,7 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
       };
       // transposed, padded lists per wave of 64 unit pairs; chunks of at most 16 waves within the LDS budget
       p->rcoef.clear(); p->ridx.clear(); p->rchunk.assign(1, 0); p->rcrow.assign(1, 0); p->rwrow.clear(); p->rchunk_rows_max = 0;
-      const long long total_pairs = (long long)U * U;
+      const long long total_pairs = lists ? (long long)U * U : 0;
       const long long lds_budget = 156 * 1024 - (long long)(p->E + p->NP) * 16 - (long long)2 * n_end * 16 - 33 * 4 - 256;
       const long long cap_rows = lds_budget > 0 ? lds_budget / (64 * 10) : 0;          // a row: 64 x (8-byte coefficient + 2-byte index)
       std::vector<int> wr(33, 0);
@@ -474,7 +483,7 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
     const int max_pairs = 1024;                                    // = FILL_SYM_THREADS: one unit pair per thread
     const long long budget = 158 * 1024 - (long long)p->H2lin * 16 - (long long)2 * n_end * 16 - (long long)(2 * max_pairs + 1) * 4 - 64;
     long long cap_terms = budget > 0 ? budget / 10 : 0;
-    const long long total = (long long)U * U;
+    const long long total = lists ? (long long)U * U : 0;
     p->qchunk.clear(); p->qchunk.push_back(0);
     p->qchunk_terms_max = 0; p->qchunk_pairs_max = 0;
     long long e0 = 0;

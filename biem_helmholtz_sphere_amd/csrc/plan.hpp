@@ -5,6 +5,8 @@
 #include <cstdint>
 #include "special.hpp"
 
+constexpr int kLists2dMax = 160;            // 2-D plans up to this order also carry term lists (tests, the generic fill forms)
+
 struct biem_plan {
   int tree = 0, d = 0, n_end = 0, n2 = 0;   // n2 = 2 n_end - 1 (degrees of the translation table)
   int H = 0, H2 = 0, Q = 0;
@@ -22,6 +24,7 @@ struct biem_plan {
   std::vector<int> chunk_ent;               // fill chunks: entries e = h*H + h' in [chunk_ent[c], chunk_ent[c+1]); sized to the LDS budget
   int chunk_terms_max = 0;                  // largest number of terms in one chunk
   int chunk_ents_max = 0;                   // largest number of entries in one chunk
+  bool lists_built = true;                  // false: 2-D beyond kLists2dMax - no term lists (ptr / coef / q* / r* are empty), only the 2-D fills run
   bool fill_table_global = false;           // general fill: the pair table stays in global memory (it does not fit LDS beside the term slice)
   // the symmetric (real-harmonic) fill: unit pairs (u, u') in row-major order, four term lists ("slots") per pair for the entries
   // (h,h'), (h,p'), (p,h'), (p,p') of the units (h,p), (h',p') - empty where h == p or h' == p' - so one thread forms a whole

@@ -382,7 +382,10 @@ def _theta4(n_end: int):
     nl = [(n, l) for n in range(n_end) for l in range(n + 1)]
     An = np.array([Ab[n, l] for (n, l) in nl])                      # [NL, q]
     A4 = np.einsum("aq,bq,nlq,q->abnl", An, An, Ab, w, optimize=True)
-    A4[np.abs(A4) < 1e-14] = 0.0          # quadrature noise on entries that vanish by the selection rules
+    # quadrature noise on entries that vanish by the selection rules.  The noise grows with the order (3e-14 at n_end = 15, where a
+    # 1e-14 cut let some of it through: 1.6e-10 in u_scat of two close spheres against the same table from a 3 n_end-node rule);
+    # entries that do not vanish are >= 1e-9 up to n_end = 15, so 1e-12 separates the two
+    A4[np.abs(A4) < 1e-12] = 0.0
     return A4, nl, Ab
 
 

@@ -196,7 +196,7 @@ def test_order_ceilings_of_the_fill(amd, golden_dir):
     (H2 = 85^2 > 7168) - the one-system-per-lane form takes over (no ceiling on the order); the solution has converged long
     before, so it must equal the n_end = 39 golden.  (3) 2-D n_end = 152 (radial tables up to order 320; the reference's 2-D
     goldens go on to n_end = 3444, beyond what is built here): high-wavenumber golden rows, k|t| up to 16384.
-    (4) one past the 2-D ceiling (n_end = 161): a clean error, no numbers."""
+    (4) 2-D beyond the former ceiling of n_end = 160, up to the reference's largest order 3444."""
     import csv
     import os
 
@@ -224,8 +224,19 @@ def test_order_ceilings_of_the_fill(amd, golden_dir):
     for k in (8.0, 64.0, 1024.0, 4096.0):
         got, want = run("a", 152, k), rows[("a2", 152, k)]
         assert abs(got - want) < 1e-9 * max(1.0, abs(want)), (k, got, want)
-    with pytest.raises(L.BiemLibraryError, match="exceeds the built table size"):
-        run("a", 161, 1.0)
+    # (4) 2-D beyond n_end = 160 (the list-free Toeplitz fill, radial recurrences in global memory): rows of the reference's
+    # accuracy sweep up to its largest order, n_end = 3444 at k = 2896.3 (N = 13774; cli.py:223)
+    for k, n_end in ((11.313708, 181), (32.0, 256), (128.0, 512), (512.0, 1024), (1024.0, 1722), (4096.0, 1722), (2896.309376, 3444)):
+        got, want = run("a", n_end, k), rows[("a2", n_end, round(k, 6))]
+        assert abs(got - want) < 1e-9 * max(1.0, abs(want)), (k, n_end, got, want)
+    # a 2-D plan of such an order holds no term lists (they would be H^2 one-term entries): the accessor says so
+    import ctypes as C
+
+    plan = C.c_void_p()
+    lib = L.load()
+    L.check(lib.biem_plan_create_host(L.TREE_IDS["a"], 200, C.byref(plan)))
+    assert lib.biem_plan_terms(plan, None, None, None) == 3 and b"no term lists" in lib.biem_last_error()
+    lib.biem_plan_destroy(plan)
 
 
 @pytest.mark.parametrize("tree,n_end,ks", [("ba", 43, (2.0, 10.0)), ("bba", 15, (2.0, 6.0))])

@@ -1025,8 +1025,8 @@ def test_sharded_solve_on_rccl_world_size_one(amd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["red", "entry", "sys"])
-@pytest.mark.parametrize("tree,n_end,B,robin", [("a", 9, 3, False), ("ba", 6, 3, True), ("ba", 12, 2, False), ("bba", 4, 3, True), ("caa", 4, 2, False)])
+@pytest.mark.parametrize("form", ["default", "red", "entry", "sys"])
+@pytest.mark.parametrize("tree,n_end,B,robin", [("a", 9, 3, False), ("a", 40, 4, True), ("ba", 6, 3, True), ("ba", 12, 2, False), ("bba", 4, 3, True), ("caa", 4, 2, False)])
 def test_symmetric_fill_vs_transformed_general_fill(amd, lib, tree, n_end, B, robin, form, monkeypatch):
     """BIEM_FILL_SYMMETRIC (what the L D L^T path factors, written once by the fused kernel) against R W^H M W R^-1 formed in
     NumPy from the general BIEM_FILL_EQUILIBRATED matrix, on everything the factorisation reads (upper triangle + diagonal
@@ -1034,7 +1034,12 @@ def test_symmetric_fill_vs_transformed_general_fill(amd, lib, tree, n_end, B, ro
     (small batches) and one system per lane (batches of >= 32 systems; forced here on a batch of 2)."""
     from biem_helmholtz_sphere_amd import _biem as impl
 
-    monkeypatch.setenv("BIEM_FILL_FORM", form)
+    # "default": what the product runs (reduced-table kernel; 2-D: the list-free Toeplitz kernels, for the general fill M as well);
+    # the named forms force the list kernels (2-D included), so for tree a the two families check each other
+    if form != "default":
+        monkeypatch.setenv("BIEM_FILL_FORM", form)
+    else:
+        monkeypatch.delenv("BIEM_FILL_FORM", raising=False)
     l, L = lib
     d = O.tree(tree).d
     rng = np.random.default_rng(n_end + B)
@@ -1088,6 +1093,45 @@ def test_symmetric_fill_vs_transformed_general_fill(amd, lib, tree, n_end, B, ro
         assert np.isfinite(got[region]).all()
         assert np.abs(got[region] - want[region]).max() < 1e-13 * np.abs(want).max(), (tree, s)
         assert np.abs(np.diag(got) - 1.0).max() < 1e-15
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["reference", "equilibrated"])
+def test_2d_toeplitz_general_fill_vs_list_kernel(amd, lib, scaling, monkeypatch):
+    """The list-free 2-D general fill (k_fill2d: one Graf term per entry evaluated directly) against the generic list kernel k_fill
+    on the same inputs, both scalings, element-wise (identical arithmetic up to the order of two multiplications)."""
+    from biem_helmholtz_sphere_amd import _biem as impl
+
+    l, L = lib
+    n_end, B, nb = 23, 4, 2
+    rng = np.random.default_rng(3)
+    cen = rng.normal(size=(B, 2)) * 0.3 + np.arange(B)[:, None] * np.array([2.4, 0.3])
+    rad = rng.uniform(0.6, 1.0, size=B)
+    ks = np.array([0.9, 2.3 + 0.2j])
+    plan = impl._plan("a", n_end, torch.device("cuda", 0))
+    N = B * plan.H
+    npad = l.biem_lu_npad(N)
+    al = _dev(np.full((1, B), 1.0 + 0.1j), torch.complex128)
+    be = _dev(np.full((1, B), 0.4 - 0.1j), torch.complex128)
+    k_t, eta_t, cen_t, rad_t = _dev(ks, torch.complex128), _dev(np.array([1.0, 0.7])), _dev(cen[None]), _dev(rad[None])
+    tab = torch.empty((nb, B, 3, n_end), dtype=torch.complex128, device="cuda")
+    L.check(l.biem_ball_tables(plan.handle, nb, B, k_t.data_ptr(), eta_t.data_ptr(), rad_t.data_ptr(), 0, al.data_ptr(), be.data_ptr(), 0, tab.data_ptr(), None))
+    wb = l.biem_fill_workspace_bytes(plan.handle, nb, B)
+    work = torch.empty(max(wb, 16), dtype=torch.uint8, device="cuda")
+    sc = L.FILL_REFERENCE if scaling == "reference" else L.FILL_EQUILIBRATED
+    out = {}
+    for name in ("direct", "lists"):
+        if name == "lists":
+            monkeypatch.setenv("BIEM_FILL_FORM", "entry")
+        else:
+            monkeypatch.delenv("BIEM_FILL_FORM", raising=False)
+        M = torch.full((nb, npad, npad), float("nan"), dtype=torch.complex128, device="cuda")
+        L.check(l.biem_fill(plan.handle, nb, B, k_t.data_ptr(), cen_t.data_ptr(), 0, tab.data_ptr(), sc, M.data_ptr(), npad, npad * npad, npad, work.data_ptr(), wb, None))
+        out[name] = M.cpu().numpy()
+    a, b = out["direct"], out["lists"]
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    nz = np.abs(b) > 0
+    assert np.max(np.abs(a - b)[nz] / np.abs(b)[nz]) < 1e-13 and np.all(a[~nz] == 0)
 
 
 # ---------------------------------------------------------------------------- the row-form symmetric factorisation (default path)
