@@ -924,7 +924,8 @@ extern "C" int biem_debug_fill_trace(unsigned long long* out, int reset) {
 
 // ---------------------------------------------------------------------------------------------
 // 2-D fills without term lists (tree a, any order).  Graf's theorem leaves ONE term per entry,
-//     S(m, m') = i^{|m| + |mu| - |m'|} T[mu],   mu = m' - m,   T[mu] = T'[|mu|] e^{i mu phi},   T'[j] = C_2 H_j(k|t|) / (2 pi),
+//     S(m, m') = i^{|m| + |mu| - |m'|} T[mu] / sqrt(2 pi),   mu = m' - m,   T[mu] = T'[|mu|] e^{i mu phi},   T'[j] = C_2 H_j(k|t|) / sqrt(2 pi)
+// (the 1 / sqrt(2 pi) in front is the triple integral of three circular harmonics - the coefficient of the plan's one-term lists),
 // so a block is a Toeplitz matrix in (m, m') up to signs: every thread evaluates its entries from the table row of the pair
 // (k_pair_tables in reduced mode: T'[0 .. 2 n_end - 2], the phases e^{i j phi}, j >= 0, and the q factors of the two balls) read
 // straight from global memory - consecutive lanes read consecutive entries, the row (at most 6 n_end complex numbers) stays in L1 /
@@ -946,8 +947,8 @@ __global__ void __launch_bounds__(256) k_fill2d_sym(int n_end, int H, int B, int
   const long long o00 = (long long)row_c * lda + col_c, o01 = (long long)row_c * lda + col_s, o10 = (long long)row_s * lda + col_c,
                   o11 = (long long)row_s * lda + col_s;
   const int muA = mp - m, jA = muA < 0 ? -muA : muA, jB = m + mp;
-  const double sA = muA >= 0 ? 1.0 : ((jA & 1) ? -1.0 : 1.0);       // i^{m + |mu| - m'}: 1 for m' >= m, (-1)^{m - m'} otherwise
-  const double sB = (m & 1) ? -1.0 : 1.0;                            // (h, p'): mu = -(m + m'), i^{2 m}
+  const double sA = (muA >= 0 ? 1.0 : ((jA & 1) ? -1.0 : 1.0)) * kInvSqrt2Pi;     // i^{m + |mu| - m'} / sqrt(2 pi): sign 1 for m' >= m, (-1)^{m - m'} otherwise
+  const double sB = ((m & 1) ? -1.0 : 1.0) * kInvSqrt2Pi;                          // (h, p'): mu = -(m + m'), i^{2 m}
   const double q2 = 0.70710678118654752440;
   const int nrep = classes[0];
   const int* dup_ptr = classes + 4 + npairs;
@@ -1027,7 +1028,7 @@ __global__ void __launch_bounds__(256) k_fill2d(int n_end, int H, int B, int npa
   const cplx* row = T + ((size_t)s * B * B + (size_t)b * B + bp) * HR;
   cplx ph = row[E + j];
   if (mu < 0) ph.y = -ph.y;
-  const cplx raw = cscale(cmul(row[j], ph), sign_even(am + j - amp));
+  const cplx raw = cscale(cmul(row[j], ph), sign_even(am + j - amp) * kInvSqrt2Pi);
   const cplx* tb = tab + ((size_t)s * B + b) * 3 * n_end;
   const cplx* tbp = tab + ((size_t)s * B + bp) * 3 * n_end;
   auto colfac = [&](const cplx* tball, int n) { return scaling == BIEM_FILL_REFERENCE ? tball[2 * n_end + n] : crecip(tball[n_end + n]); };
