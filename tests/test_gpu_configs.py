@@ -226,7 +226,7 @@ def test_order_ceilings_of_the_fill(amd, golden_dir):
         assert abs(got - want) < 1e-9 * max(1.0, abs(want)), (k, got, want)
     # (4) 2-D beyond n_end = 160 (the list-free Toeplitz fill, radial recurrences in global memory): rows of the reference's
     # accuracy sweep up to its largest order, n_end = 3444 at k = 2896.3 (N = 13774; cli.py:223)
-    for k, n_end in ((11.313708, 181), (32.0, 256), (128.0, 512), (512.0, 1024), (1024.0, 1722), (4096.0, 1722), (2896.309376, 3444)):
+    for k, n_end in ((2.0 ** 3.5, 181), (32.0, 256), (128.0, 512), (512.0, 1024), (1024.0, 1722), (4096.0, 1722), (2.0 ** 11.5, 3444)):
         got, want = run("a", n_end, k), rows[("a2", n_end, round(k, 6))]
         assert abs(got - want) < 1e-9 * max(1.0, abs(want)), (k, n_end, got, want)
     # a 2-D plan of such an order holds no term lists (they would be H^2 one-term entries): the accessor says so
