@@ -154,7 +154,8 @@ __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int
                                                      int lower, int nbp, const int* __restrict__ lin2, int H2lin,
                                                      const int* __restrict__ red_of = nullptr, const int* __restrict__ red_first = nullptr,
                                                      const int* __restrict__ ph_mu = nullptr, int E = 0, int NP = 0,
-                                                     const cplx* __restrict__ tab = nullptr, int n_end = 0, cplx* __restrict__ rad_scratch = nullptr) {
+                                                     const cplx* __restrict__ tab = nullptr, int n_end = 0, cplx* __restrict__ rad_scratch = nullptr,
+                                                     const int* __restrict__ rep_flag = nullptr) {
   __shared__ cplx sJl[kMaxRad * 2 + 6];
   __shared__ cplx sHl[kMaxRad * 2 + 6];
   int pair = blockIdx.x, s = blockIdx.y;
@@ -166,6 +167,7 @@ __global__ void __launch_bounds__(64) k_pair_tables(int tree, int d, int n2, int
   // both fills contract the blocks b < bp (the general fill derives block (bp, b) from (b, bp) by the parity sign, the symmetric
   // fill writes the upper triangle only); lower = 1 (tables of the pairs b > bp instead) is kept for tests
   if (lower ? b <= bp : b >= bp) return;
+  if (rep_flag != nullptr && !rep_flag[b * B + bp]) return;      // pair classes: only a class's first pair is read by the fill
   const double* cb = centers + ((geom_batched ? (size_t)s * B : 0) + b) * d;
   const double* cp = centers + ((geom_batched ? (size_t)s * B : 0) + bp) * d;
   double t[4];
@@ -413,7 +415,8 @@ static bool fill_red_fits(const biem_plan* p, size_t* shm_out) {
 }
 
 // pair classes of the symmetric fill (k_pair_dedupe), behind the pair tables: nrep (+3 pad), rep_list[np], dup_ptr[np + 1], dup_bb[np]
-static size_t fill_dedupe_bytes(int B) { const size_t np = (size_t)B * (B - 1) / 2; return ((3 * np + 5) * sizeof(int) + 15) / 16 * 16; }
+// ... then rep_flag[B * B]: 1 where the pair (b, bp) is the first of its class - only those pairs' tables are read by the fill
+static size_t fill_dedupe_bytes(int B) { const size_t np = (size_t)B * (B - 1) / 2; return ((3 * np + 5 + (size_t)B * B) * sizeof(int) + 15) / 16 * 16; }
 constexpr int kDedupeMaxPairs = 2048;       // (the class search is quadratic in the pairs, in one workgroup)
 
 size_t fill_workspace_bytes(const biem_plan* p, int nb, int B) {
@@ -433,7 +436,7 @@ __global__ void k_fill2d(int n_end, int H, int B, int npairs, const cplx* __rest
 // k_pair_tables in reduced mode (table rows T' | phases | q factors); 2-D orders whose radial arrays exceed the kernel's LDS take
 // stream-ordered global scratch
 static int launch_pair_tables_red(const biem_plan* p, int nb, int B, const double* d_k, const double* d_centers, int geom_batched,
-                                  const double* d_tab, cplx* T, hipStream_t st) {
+                                  const double* d_tab, cplx* T, hipStream_t st, const int* rep_flag = nullptr) {
   cplx* scratch = nullptr;
   if (p->n2 + 6 > kMaxRad * 2 + 6) {
     if (p->tree != TREE_A) { set_error("n_end=%d exceeds the built table size", p->n_end); return BIEM_ERR_UNSUPPORTED; }
@@ -441,7 +444,7 @@ static int launch_pair_tables_red(const biem_plan* p, int nb, int B, const doubl
   }
   hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2, p->d_deg2, B,
                      (const cplx*)d_k, d_centers, geom_batched, T, 0, 0, nullptr, 0, p->d_red_of, p->d_red_first, p->d_ph_mu, p->E, p->NP,
-                     (const cplx*)d_tab, p->n_end, scratch);
+                     (const cplx*)d_tab, p->n_end, scratch, rep_flag);
   BIEM_LAUNCHCHK();
   if (scratch) BIEM_HIPCHK(hipFreeAsync(scratch, st));
   return BIEM_OK;
@@ -530,7 +533,9 @@ __global__ void __launch_bounds__(256) k_pair_dedupe(int B, int d, int npairs, c
   int* rep_list = out + 4;
   int* dup_ptr = rep_list + npairs;
   int* dup_bb = dup_ptr + npairs + 1;
+  int* rep_flag = dup_bb + npairs;            // [B * B]
   const int tid = threadIdx.x;
+  for (int e = tid; e < B * B; e += 256) rep_flag[e] = enable ? 0 : 1;
   auto pair_of = [&](int pr, int& b, int& bp) {
     int bb = (int)((sqrtf(8.0f * (float)pr + 1.0f) + 1.0f) * 0.5f);
     while (bb * (bb - 1) / 2 > pr) --bb;
@@ -581,7 +586,8 @@ __global__ void __launch_bounds__(256) k_pair_dedupe(int B, int d, int npairs, c
     for (int p = 0; p < npairs; ++p) cnt[rep[p]]++;
     int nrep = 0, pos = 0;
     for (int p = 0; p < npairs; ++p)
-      if (rep[p] == p) { rep_list[nrep] = p; dup_ptr[nrep] = pos; pos += cnt[p]; cnt[p] = dup_ptr[nrep]; rep[p] = -nrep - 1; ++nrep; }   // rep[p] < 0: class index
+      if (rep[p] == p) { rep_list[nrep] = p; dup_ptr[nrep] = pos; pos += cnt[p]; cnt[p] = dup_ptr[nrep]; rep[p] = -nrep - 1; ++nrep;   // rep[p] < 0: class index
+                         int b, bp; pair_of(p, b, bp); rep_flag[b * B + bp] = 1; }
     dup_ptr[nrep] = pos;
     out[0] = nrep;
     for (int p = 0; p < npairs; ++p) {           // pairs in ascending order: the representative is the first of its class
@@ -1194,7 +1200,6 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
   if (direct2d && B > 1) {
     // 2-D: the list-free kernel (any order); pair classes as in the list forms
     if (!plan_2d_direct(p)) { set_error("biem_fill (symmetric): internal: 2-D table order"); return BIEM_ERR_ARG; }
-    { const int rc = launch_pair_tables_red(p, nb, B, d_k, d_centers, geom_batched, d_tab, T, st); if (rc) return rc; }
     const int npairs = B * (B - 1) / 2;
     int* classes = (int*)((char*)d_work + fill_workspace_bytes(p, nb, B) - fill_dedupe_bytes(B));
     const char* mn = getenv("BIEM_FILL_DEDUPE_MIN");
@@ -1204,6 +1209,8 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
     hipLaunchKernelGGL(k_pair_dedupe, dim3(1), dim3(256), shm_dd, st, B, p->d, npairs, d_centers,
                        on ? dedupe->radii : nullptr, on ? dedupe->alpha : nullptr, on ? dedupe->beta : nullptr, on ? 1 : 0, classes);
     BIEM_LAUNCHCHK();
+    // (the pair tables of the class heads only: the serial radial recurrence of a pair's table is the expensive part of a 2-D fill)
+    { const int rc = launch_pair_tables_red(p, nb, B, d_k, d_centers, geom_batched, d_tab, T, st, classes + 4 + 3 * npairs + 1); if (rc) return rc; }
     const long long ncomb = (long long)npairs * nb;
     const unsigned gx = (unsigned)(((long long)U * U + 255) / 256);
     long long gy = ncomb < 65535 ? ncomb : 65535;
@@ -1254,14 +1261,6 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
       set_error("biem_fill (symmetric, one unit pair per lane): tables do not fit LDS (n_end=%d: H2=%d, chunk terms=%d)", p->n_end, p->H2, p->qchunk_terms_max);
       return BIEM_ERR_UNSUPPORTED;
     }
-    if (use_red)
-      hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2, p->d_deg2, B,
-                         (const cplx*)d_k, d_centers, geom_batched, T, 0, 0, nullptr, 0, p->d_red_of, p->d_red_first, p->d_ph_mu, p->E, p->NP,
-                         (const cplx*)d_tab, p->n_end);
-    else
-      hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2, p->d_deg2, B,
-                         (const cplx*)d_k, d_centers, geom_batched, T, 0, 0, p->d_lin2, p->H2lin);
-    BIEM_LAUNCHCHK();
     const int npairs = B * (B - 1) / 2;
     const long long ncomb = (long long)npairs * nb;
     int* classes = (int*)((char*)d_work + fill_workspace_bytes(p, nb, B) - fill_dedupe_bytes(B));
@@ -1274,6 +1273,16 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
       if (shm_dd > 48 * 1024) BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_pair_dedupe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_dd));
       hipLaunchKernelGGL(k_pair_dedupe, dim3(1), dim3(256), shm_dd, st, B, p->d, npairs, d_centers,
                          on ? dedupe->radii : nullptr, on ? dedupe->alpha : nullptr, on ? dedupe->beta : nullptr, on ? 1 : 0, classes);
+      BIEM_LAUNCHCHK();
+    }
+    // pair tables, of the class heads only (the fill reads no others)
+    const int* rep_flag = classes + 4 + 3 * npairs + 1;
+    if (use_red) {
+      const int rc = launch_pair_tables_red(p, nb, B, d_k, d_centers, geom_batched, d_tab, T, st, rep_flag);
+      if (rc) return rc;
+    } else {
+      hipLaunchKernelGGL(k_pair_tables, dim3(B * B, nb), dim3(64), 0, st, p->tree, p->d, p->n2, p->H2, p->Cd, p->d_labels2, p->d_deg2, B,
+                         (const cplx*)d_k, d_centers, geom_batched, T, 0, 0, p->d_lin2, p->H2lin, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, rep_flag);
       BIEM_LAUNCHCHK();
     }
     // enough workgroups to fill the chip a few times over, each with a long loop over combinations
