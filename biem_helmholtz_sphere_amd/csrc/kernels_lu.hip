@@ -1909,40 +1909,6 @@ __global__ void __launch_bounds__(DIAG_THREADS) k_diag_utu_reg(cplx* __restrict_
   if (tid == 0 && bad && info[s] == 0) info[s] = -(j + 1);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Fused strip pass of the panels b, c, d of a group (row form).  With P = U[J .. jq, jq .. jq+64) (the group's earlier strips above
-// the diagonal block), Q = U[J .. jq, cols) and X = U11^{-T} of the panel at jq, the panel's strip is
-//     U12 = X (C - P^T Q) = C - [ (X P^T) | W ] [ Q ; C ],      W = I - X,
-// i.e. ONE zgemm pass with K = 64 (q + 1) whose B operand is the matrix rows J .. jq+64 as they lie (Q, then the strip's own rows)
-// and whose A operand [k][i] is (P X^T)[k][i] for the 64 q rows of Q and W[k][i] for the strip's own: the strip is read and written
-// once per panel instead of twice (pending-update pass, then the solve).  This kernel forms that A operand per system:
-// Wbig[k][i] = sum_c P[k][c] X[i][c] (k < 64 q), Wbig[64 q + k][i] = W[k][i].  One 256-thread workgroup per system.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_strip_operand(const cplx* __restrict__ A, long long lda, long long sys_stride, int J, int jq,
-                                                        const cplx* __restrict__ Wt, cplx* __restrict__ Wbig) {
-  __shared__ cplx sX[NB][NB + 1];            // X[i][c] = delta_ic - W[c][i]
-  const int s = blockIdx.x, tid = threadIdx.x;
-  const cplx* Ws = Wt + (size_t)s * NB * NB;
-  cplx* Wo = Wbig + (size_t)s * 4 * NB * NB;
-  const int kq = jq - J;                      // 64 q rows of Q
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int c = e >> 6, i = e & 63;         // W[c][i]
-    const cplx w = Ws[e];
-    sX[i][c] = make_double2((i == c ? 1.0 : 0.0) - w.x, -w.y);
-    Wo[(size_t)(kq + c) * NB + i] = w;        // the strip's own rows: W as it is
-  }
-  __syncthreads();
-  const cplx* Ps = A + (size_t)s * sys_stride + (size_t)J * lda + jq;       // P[k][c] = U[J + k][jq + c]
-  for (int e = tid; e < kq * NB; e += 256) {
-    const int k = e >> 6, i = e & 63;
-    const cplx* pk = Ps + (size_t)k * lda;
-    cplx acc = make_double2(0.0, 0.0);
-#pragma unroll 8
-    for (int c = 0; c < NB; ++c) acc = cfma(pk[c], sX[i][c], acc);
-    Wo[(size_t)k * NB + i] = acc;
-  }
-}
-
 bool sym_small_path(int n_active, int nrhs) {
   return n_active > 0 && n_active <= SMALL_N_MAX && nrhs <= SMALL_RHS_MAX && n_active + nrhs <= 128 && small_utu_lds(n_active, nrhs) <= 160 * 1024 - 2048 &&
          !getenv("BIEM_NO_SMALL_PATH");
@@ -2010,35 +1976,20 @@ int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long 
     if (n_cols > j + NB)
       gemm(st, nb, A, lda, sys_stride, Wt - j, NB, (long long)NB * NB, j, j + NB, j + NB, n_cols, j, NB, PK_PANEL, 8.0 * (double)nb * (n_cols - j - NB) * NB * NB);
   };
-  // BIEM_STRIP_FORM=split (A / B runs): the panels b, c, d take the group's pending updates in one pass over their 64 rows and the
-  // strip solve in a second one; default: one fused pass (k_strip_operand)
-  const char* sf = getenv("BIEM_STRIP_FORM");
-  const bool fused_strip = !(sf && sf[0] == 's');
-  cplx* Wbig = (cplx*)d_work;                       // [nb][4 * 64][64]: the panel region of the workspace is free until the back substitution
+  // (A fused form - the diagonal block updated alone, then ONE pass U12 = C - [(X P^T) | W] [Q ; C] with K = 64 (q + 1) over the strip
+  // instead of the pending-update pass and the solve pass - was built and measured in round 3: these passes run at the zgemm
+  // pipeline's rate per K-chunk like the bulk update (0.445 / 0.79 / 1.22 ms for K = 64 / 128 / 192 at cfg 3), not at a bandwidth
+  // limit, so the same K-chunks in fewer passes gain 2.5 % of panel + in-group time at cfg 3, nothing at cfg 5, and lose 27 % at
+  // cfg 4 and 30 % for one system per call (three more small launches per panel).  Not kept)
   for (int J = 0; J < n_pad; J += 4 * NB) {
     const cplx* strip = A + (size_t)J * lda;        // both operands of this group's updates: rows J .. of the matrix itself
     panel(J);
     for (int q = 1; q < 4; ++q) {
       const int jq = J + q * NB;
       if (jq >= n_pad) break;
-      if (!fused_strip) {
-        // the next panel's 64 rows: all pending updates of the group (K = 64 q), every column right of them incl. the right-hand sides
-        gemm(st, nb, A, lda, sys_stride, strip, lda, sys_stride, jq, jq + NB, jq, n_cols, J, q * NB, PK_OTHER);
-        panel(jq);
-        continue;
-      }
-      // the diagonal block alone takes the pending updates (one tile per system), is factored, and the strip right of it gets the
-      // pending updates and the solve in ONE pass: U12 = C - [(X P^T) | W] [Q ; C]
-      gemm(st, nb, A, lda, sys_stride, strip, lda, sys_stride, jq, jq + NB, jq, jq + NB, J, q * NB, PK_OTHER);
-      {
-        ProfScope ps(PK_PANEL, st, 0.0);
-        hipLaunchKernelGGL(k_diag_utu_reg, dim3(nb), dim3(DIAG_THREADS), DIAG_LDS_CPLX * sizeof(cplx), st, A, lda, sys_stride, jq, Wt, d_info, nopiv, growth);
-        if (n_cols > jq + NB)
-          hipLaunchKernelGGL(k_strip_operand, dim3(nb), dim3(256), 0, st, A, lda, sys_stride, J, jq, Wt, Wbig);
-      }
-      if (n_cols > jq + NB)
-        gemm(st, nb, A, lda, sys_stride, Wbig - jq, NB, (long long)4 * NB * NB, jq, jq + NB, jq + NB, n_cols, J, (q + 1) * NB, PK_OTHER,
-             8.0 * (double)nb * (n_cols - jq - NB) * NB * (double)((q + 1) * NB));
+      // the next panel's 64 rows: all pending updates of the group (K = 64 q), every column right of them incl. the right-hand sides
+      gemm(st, nb, A, lda, sys_stride, strip, lda, sys_stride, jq, jq + NB, jq, n_cols, J, q * NB, PK_OTHER);
+      panel(jq);
     }
     if (J + 4 * NB >= n_pad) break;
     gemm(st, nb, A, lda, sys_stride, strip, lda, sys_stride, J + 4 * NB, n_pad, J + 4 * NB, n_pad, J, 4 * NB, PK_GEMM, -1.0, nullptr, 0, 0, 0,

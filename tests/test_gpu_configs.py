@@ -307,4 +307,7 @@ def test_matrix_attribute_beyond_the_lds_ceiling(amd):
             assert np.abs(Mb - Ab).max() < 1e-12 * np.abs(Ab).max(), (b, bp)
             nz = np.abs(Ab) > 1e-200
             assert np.max(np.abs(Mb - Ab)[nz & low] / np.abs(Ab)[nz & low]) < 1e-9, (b, bp)
-            assert np.all(Mb[~nz] == 0)
+            if b == bp:
+                assert np.all(Mb[~nz] == 0)                     # a ball's own block: exactly diagonal
+            else:
+                assert np.all(np.abs(Mb[~nz]) < 1e-30 * np.abs(Ab).max())   # (entries the oracle's products underflow on: 1e-37 here)
