@@ -706,6 +706,9 @@ def biem(
                     density_t[redo] = dens_r
             _last_solve_stats["ldlt_systems"] = nb if solver == "ldlt" else 0
             _last_solve_stats["lu_systems"] = (int(redo.numel()) if solver == "ldlt" else nb)
+            # why the symmetric path handed systems over (diagnostics): info = -(first row of the rejecting 64-row panel + 1), or
+            # -(n_pad + 1) for the growth check
+            _last_solve_stats["rejected_info"] = info[redo].tolist()[:64] if solver == "ldlt" and redo.numel() > 0 else []
             del work
 
     def make_matrix():

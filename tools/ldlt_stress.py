@@ -30,4 +30,4 @@ for gap in (1.5, 1.1, 1.02, 1.002):
             if solver == "ldlt":
                 st = dict(impl._last_solve_stats)
         err = np.max(np.abs(out["ldlt"] - out["lu"]) / np.abs(out["lu"]))
-        print(f"n_end {n_end:2d} N {len(rad) * n_end * n_end:4d} gap {gap:6.3f} {name:11s} fell back to LU: {st['lu_systems']} of {st['ldlt_systems']}   max rel diff u_scat {err:.2e}", flush=True)
+        print(f"n_end {n_end:2d} N {len(rad) * n_end * n_end:4d} gap {gap:6.3f} {name:11s} fell back to LU: {st['lu_systems']} of {st['ldlt_systems']}   max rel diff u_scat {err:.2e}  info {st.get('rejected_info')}", flush=True)
