@@ -163,6 +163,8 @@ def _origin_of(*arrays: Any) -> Tuple[_Origin, torch.device]:
 def _to_dev(a: Any, dev: torch.device, dtype: Any) -> torch.Tensor:
     if isinstance(a, torch.Tensor):
         return a.to(device=dev, dtype=dtype)
+    if isinstance(a, (int, float, complex)):           # Python scalars: a fill kernel instead of a (synchronous, pageable) host copy
+        return torch.full((), a, dtype=dtype, device=dev)
     return torch.as_tensor(np.asarray(a), device=dev).to(dtype)
 
 
@@ -635,9 +637,12 @@ def biem(
     g = None
     full, op_axes, rhs_axes, nrhs = tuple(batch), list(range(len(batch))), [], 1
     if has_rhs:
-        if not bool(torch.all(alpha_t == 0)) and uin is None:
+        # (the all-zero tests are only needed when the matching callable is missing; Python scalars are decided on the host)
+        def _all_zero(v, v_t):
+            return (v == 0) if isinstance(v, (int, float, complex)) else bool(torch.all(v_t == 0))
+        if uin is None and not _all_zero(alpha, alpha_t):
             raise ValueError("alpha is not zero, but uin is None. uin must be provided to compute the boundary condition.")
-        if not bool(torch.all(beta_t == 0)) and uin_grad is None:
+        if uin_grad is None and not _all_zero(beta, beta_t):
             raise ValueError("beta is not zero, but uin_grad is None. uin_grad must be provided to compute the boundary condition.")
         g, full, op_axes, rhs_axes = _boundary_samples(plan, origin, fl, batch, uin, uin_grad, perm)
         nrhs = int(g.shape[1])

@@ -643,7 +643,7 @@ def test_batched_geometry_and_points_per_system(amd, force_lu_fallback, monkeypa
         monkeypatch.setenv("BIEM_LDLT_PIVOT_REL", "1e30")
     calc = amd.biem(c, centers=_dev(cen), radii=_dev(rad), k=_dev(ks), n_end=8, alpha=0.0, beta=1.0, uin=uin, uin_grad=ugr)
     from biem_helmholtz_sphere_amd import _biem as impl
-    assert impl._last_solve_stats == {"ldlt_systems": K, "lu_systems": K if force_lu_fallback else 0}
+    assert {q: impl._last_solve_stats[q] for q in ("ldlt_systems", "lu_systems")} == {"ldlt_systems": K, "lu_systems": K if force_lu_fallback else 0}
     xs = 6.0 + rng.normal(size=(K, 4, 3))                               # [K, P, d]
     u = calc.uscat(_dev(np.transpose(xs, (2, 1, 0))), expand_x=False).cpu().numpy()      # (d, P, K) -> [P, K]
     assert u.shape == (4, K)
@@ -716,8 +716,8 @@ def test_ldlt_rejected_pivot_is_reported(lib):
     N = 128
     A = np.zeros((2, N, N + 8), dtype=np.complex128)
     A[:, :, :N] = np.eye(N)
-    A[1, 70, 70] = 0.01
-    A[1, 90, 70] = A[1, 70, 90] = 1.0                           # the diagonal is 1 % of its column's maximum
+    A[1, 70, 70] = 0.001
+    A[1, 90, 70] = A[1, 70, 90] = 1.0                           # the diagonal is 0.1 % of its column's maximum (limit: 1 %)
     dA = _dev(A, torch.complex128)
     ipiv = torch.zeros((2, N), dtype=torch.int32, device="cuda")
     info = torch.zeros(2, dtype=torch.int32, device="cuda")
@@ -773,34 +773,44 @@ def test_ldlt_near_a_resonance_and_forced_fallback(amd, monkeypatch):
         if rel is not None:
             monkeypatch.setenv("BIEM_LDLT_PIVOT_REL", rel)
         calc = amd.biem(c, centers=_dev(cen)[None], radii=_dev(rad)[None], k=_dev(ks), eta=_dev(np.ones(2)), n_end=7, uin=uin)
-        assert impl._last_solve_stats == stats
+        assert {q: impl._last_solve_stats[q] for q in ("ldlt_systems", "lu_systems")} == stats
         u = calc.uscat(_dev(x.T.copy())).cpu().numpy()
         for i in range(2):
             assert np.abs(u[:, i] - uo[i]).max() / np.abs(uo[i]).max() < 1e-10
 
 
 @pytest.mark.gpu
-def test_ldlt_natural_fallback_close_spheres(amd, monkeypatch):
-    """Two unit spheres 0.04 apart: at k = 0.5 the coupling is strong enough that some diagonal pivot is rejected (a multiplier
-    above 10) and that system - only that one - goes to the pivoted LU (tools/ldlt_stress.py surveys gaps and wavenumbers);
-    both routes agree with the LU-only path to rounding."""
+def test_close_spheres_stay_on_the_symmetric_path(amd, monkeypatch):
+    """Two unit spheres 0.04 apart, Robin rows: at low wavenumbers the first pivot of the second sphere (its monopole after the first
+    sphere's elimination) is small - multipliers of 11 (k = 0.5) to 76 (k -> 0), growth 8 .. 45.  The factorisation without interchanges
+    solves these to rounding (accepted since round 3: multipliers <= 100, growth <= 200; rejected and sent to the pivoted LU with the
+    round-2 limit of 10), so no system leaves the symmetric path, and both paths agree (tools/ldlt_stress.py surveys more)."""
     from biem_helmholtz_sphere_amd import _biem as impl
 
     c = amd.create_from_branching_types("ba")
     cen, rad = np.array([[0.0, 1.02, 0.0], [0.0, -1.02, 0.0]]), np.array([1.0, 1.0])
-    ks = np.array([0.5, 10.0])
-    dirs = np.zeros((3, 2)); dirs[0] = 1.0
+    ks = np.array([0.01, 0.5, 10.0])
+    dirs = np.zeros((3, 3)); dirs[0] = 1.0
     x = np.array([[6.0, 3.0, 0.1], [-5.0, 2.0, 1.0], [0.2, 7.0, -1.0]]).T
     out = {}
     for solver in ("ldlt", "lu"):
         monkeypatch.setenv("BIEM_SOLVER", solver)
         uin, ugr = amd.plane_wave(k=_dev(ks), direction=_dev(dirs))
-        calc = amd.biem(c, centers=_dev(cen)[None], radii=_dev(rad)[None], k=_dev(ks), eta=_dev(np.ones(2)), n_end=14, alpha=1.0, beta=0.3,
+        calc = amd.biem(c, centers=_dev(cen)[None], radii=_dev(rad)[None], k=_dev(ks), eta=_dev(np.ones(3)), n_end=14, alpha=1.0, beta=0.3,
                         uin=uin, uin_grad=ugr)
         out[solver] = calc.uscat(_dev(x.copy())).cpu().numpy()
         if solver == "ldlt":
-            assert impl._last_solve_stats == {"ldlt_systems": 2, "lu_systems": 1}
+            st = dict(impl._last_solve_stats)
+            assert (st["ldlt_systems"], st["lu_systems"]) == (3, 0), st
     assert np.max(np.abs(out["ldlt"] - out["lu"]) / np.abs(out["lu"])) < 1e-12
+    # the round-2 limit (multipliers <= 10) hands the k = 0.01 and k = 0.5 systems to the pivoted LU: the fallback route still works
+    monkeypatch.setenv("BIEM_SOLVER", "ldlt")
+    monkeypatch.setenv("BIEM_LDLT_PIVOT_REL", "0.1")
+    uin, ugr = amd.plane_wave(k=_dev(ks), direction=_dev(dirs))
+    calc = amd.biem(c, centers=_dev(cen)[None], radii=_dev(rad)[None], k=_dev(ks), eta=_dev(np.ones(3)), n_end=14, alpha=1.0, beta=0.3, uin=uin, uin_grad=ugr)
+    st = dict(impl._last_solve_stats)
+    assert st["lu_systems"] == 2 and st["rejected_info"] == [-193, -193], st      # the panel of the second sphere's first unknowns
+    assert np.max(np.abs(calc.uscat(_dev(x.copy())).cpu().numpy() - out["lu"]) / np.abs(out["lu"])) < 1e-12
 
 
 # ---------------------------------------------------------------------------- round 2: growth check, factor / solve split, inner kind
@@ -1174,7 +1184,7 @@ def test_sym_factor_solve_vs_numpy(lib, N, nb, nrhs):
 
 @pytest.mark.gpu
 def test_sym_factor_rejections_and_growth(lib, monkeypatch):
-    """Acceptance tests of the row form: a diagonal below a tenth of an entry of its row (a multiplier above 10) marks the system with
+    """Acceptance tests of the row form: a diagonal below a hundredth of an entry of its row (a multiplier above 100) marks the system with
     the panel's first row; max |u_ii u_ic| / max |a_ij| (moduli) equals the NumPy value - limits 1 % below / above it mark / pass
     the system (info = -(Npad + 1)); a NaN marks it at the default limit."""
     l, L = lib
@@ -1192,9 +1202,9 @@ def test_sym_factor_rejections_and_growth(lib, monkeypatch):
     N = 128
     A = np.zeros((3, N, N + 8), dtype=np.complex128)
     A[:, :, :N] = np.eye(N)
-    A[1, 70, 70] = 0.01
+    A[1, 70, 70] = 0.001
     A[1, 90, 70] = A[1, 70, 90] = 1.0                           # inside the second diagonal block
-    A[2, 10, 10] = 0.01
+    A[2, 10, 10] = 0.001
     A[2, 10, 100] = A[2, 100, 10] = 1.0                         # multiplier in the strip right of the first block
     assert run(A) == [0, -65, -1]
     N, npad = 200, 256
@@ -1223,7 +1233,7 @@ def test_sym_factor_rejections_and_growth(lib, monkeypatch):
     A = np.zeros((4, N, N + 8), dtype=np.complex128)
     A[:, :, :N] = np.eye(N)
     A[:, :, N] = 1.0
-    A[1, 10, 10] = 0.01
+    A[1, 10, 10] = 0.001
     A[1, 10, 50] = A[1, 50, 10] = 1.0
     A[2, 63, 63] = 0.0
     A[3, 5, 40] = A[3, 40, 5] = 0.4                             # multiplier 0.4: accepted
