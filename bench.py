@@ -398,12 +398,16 @@ def main() -> int:
         return None
 
     traffic, traffic_src = None, None
-    tj = profile_json("r02_gemm_traffic.json") or profile_json("r01_gemm_traffic.json")
+    tname = next((n for n in ("r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json") if profile_json(n)), None)
+    tj = profile_json(tname) if tname else None
     if tj and cfg == 3:
         key = "bytes_per_launch_per_system" if solver == "ldlt" else "bytes_per_launch_per_system_lu"
-        traffic = tj[key] * min(nloc, args.chunk or nloc)
-        traffic_src = (f"profiles/{'r02' if profile_json('r02_gemm_traffic.json') else 'r01'}_gemm_traffic.json: rocprofv3 --pmc passes at "
-                       f"{tj.get('systems_per_launch', 8)} systems per launch (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), scaled to {min(nloc, args.chunk or nloc)} systems per launch; not measured in this run")
+        per = min(nloc, args.chunk or nloc)
+        traffic = tj[key] * per
+        same = solver == "ldlt" and tj.get("systems_per_launch") == per
+        traffic_src = (f"profiles/{tname}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs of this bench.py; FETCH_SIZE doubled per the gfx950 "
+                       f"correction) at {tj.get('systems_per_launch', 8)} systems per launch"
+                       + (" = this run's launch shape" if same else f", scaled to {per} systems per launch") + "; counters cannot be read inside the timed run")
     fj = profile_json("r02_fill_traffic.json")
     fill_traffic = fj["bytes_per_system"] * nloc if fj and cfg == 3 else None
 
