@@ -713,7 +713,9 @@ def biem(
             _last_solve_stats["lu_systems"] = (int(redo.numel()) if solver == "ldlt" else nb)
             # why the symmetric path handed systems over (diagnostics): info = -(first row of the rejecting 64-row panel + 1), or
             # -(n_pad + 1) for the growth check
-            _last_solve_stats["rejected_info"] = info[redo].tolist()[:64] if solver == "ldlt" and redo.numel() > 0 else []
+            _last_solve_stats.pop("rejected_info", None)
+            if solver == "ldlt" and redo.numel() > 0:
+                _last_solve_stats["rejected_info"] = info[redo].tolist()[:64]
             del work
 
     def make_matrix():
