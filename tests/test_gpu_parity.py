@@ -566,6 +566,30 @@ def test_uscat_point_per_lane_matches_generic(amd, bt, d, n_end, B, monkeypatch)
         assert np.max(np.abs(f[ok] - g[ok])) < 1e-12 * np.max(np.abs(g[ok])), i
 
 
+def test_pair_classes_at_the_top_of_the_2d_range(amd, monkeypatch):
+    """Pair classes match displacements within 32 ulp of the largest coordinate; the block of a class is its representative's, so a
+    member's table is evaluated at a displacement off by up to that much: a phase error of k x (32 ulp) in H_n(k|t|) e^{i mu phi}.  The
+    worst case the build supports is 2-D at k |t| ~ 1e4: a 2 x 3 lattice with a pitch that is no binary fraction (displacements
+    equal to rounding only) at k = 1024 (k |t| up to 1.1e4), n_end = 152, with classes (forced for this small batch) and without -
+    densities agree to 1e-10 of their largest entry, the tolerance of the whole path (measured: 1e-12)."""
+    c = amd.create_from_branching_types("a")
+    gx, gy = np.meshgrid(np.arange(2) * 3.7 + 0.1, np.arange(3) * 3.7 - 0.3, indexing="ij")
+    cen = np.stack([gx.ravel(), gy.ravel()], -1)
+    ks = np.array([1024.0, 724.0773439350247])
+    dirs = np.zeros((2, 2)); dirs[0] = 1.0
+    dens = []
+    for off in (False, True):
+        monkeypatch.setenv("BIEM_FILL_DEDUPE_MIN", "1")
+        if off:
+            monkeypatch.setenv("BIEM_FILL_NO_DEDUPE", "1")
+        else:
+            monkeypatch.delenv("BIEM_FILL_NO_DEDUPE", raising=False)
+        uin, _ = amd.plane_wave(k=_dev(ks), direction=_dev(dirs))
+        dens.append(amd.biem(c, centers=_dev(cen)[None], radii=_dev(np.ones(6))[None], k=_dev(ks), n_end=152, uin=uin).density.cpu().numpy())
+    err = np.abs(dens[0] - dens[1]).max(axis=(1, 2)) / np.abs(dens[1]).max(axis=(1, 2))
+    assert np.all(np.isfinite(dens[0])) and err.max() < 1e-10, err
+
+
 def test_symmetric_fill_pair_classes(amd, monkeypatch):
     """Ball pairs with the same displacement vector and the same (radius, alpha, beta) on either side share their block of the
     symmetric matrix: it is contracted once and stored to every pair of the class (k_pair_dedupe).  A 3 x 2 lattice where the classes

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Turn the output of tools/collect_evidence.sh (gpurun_out/ev/) into the committed evidence files under profiles/ (prefix r02_).
+"""Turn the output of tools/collect_evidence.sh (gpurun_out/ev/) into the committed evidence files under profiles/ (prefix r03_).
 
     python tools/summarise_evidence.py [gpurun_out/ev] [profiles]
 """
@@ -12,7 +12,7 @@ import sys
 
 ev = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/ev"
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles"
-P = "r02_"
+P = "r03_"
 
 
 def line_of(path):
