@@ -409,7 +409,7 @@ static bool fill_sym_entry_fits(const biem_plan* p, size_t* shm_out) {
 
 // the reduced-table form (k_fill_red): reduced pair table + phases, q factors and the chunk's transposed lists in LDS
 static bool fill_red_fits(const biem_plan* p, size_t* shm_out) {
-  const size_t shm = (size_t)(p->E + p->NP + 2 * p->n_end) * sizeof(cplx) + (size_t)p->rchunk_rows_max * 64 * 10 + 33 * 4 + 64;
+  const size_t shm = (size_t)2 * (p->E + p->NP + 2 * p->n_end) * sizeof(cplx) + (size_t)p->rchunk_rows_max * 64 * 10 + 33 * 4 + 64;   // two table rows
   if (shm_out) *shm_out = shm;
   return p->red_lists_ok && shm <= 158 * 1024 && p->E + p->NP + 2 * p->n_end <= 8 * 1024;
 }
@@ -756,7 +756,7 @@ __device__ unsigned long long g_fill_trace[8];
 #else
 #define BIEM_FT(i)
 #endif
-template <int KT>
+template <int KT, int NC>
 __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int HR, int E, int NP, int n_end, int B, int nb, int npairs,
                                                                 const int* __restrict__ deg, const int* __restrict__ units,
                                                                 const int* __restrict__ spos, const int* __restrict__ rchunk,
@@ -767,8 +767,10 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
                                                                 cplx* __restrict__ A, long long lda, long long sys_stride,
                                                                 const int* __restrict__ classes) {
   extern __shared__ char smem[];
-  cplx* sT = (cplx*)smem;                                  // [HR = E + NP + 2 n_end] table row of the current combination: T', phases, q factors
-  double* sCoef = (double*)(sT + HR);                      // [rows_max][64]
+  // NC = 2: TWO combinations per iteration - the coefficient and index reads of a group of rows feed both tables (a fifth less LDS
+  // traffic per term: 21 instead of 26 bytes) and the barriers, the loop head and the list walk are paid once for two blocks
+  cplx* sT = (cplx*)smem;                                  // [NC][HR = E + NP + 2 n_end] table rows of the current combinations: T', phases, q factors
+  double* sCoef = (double*)(sT + (size_t)NC * HR);         // [rows_max][64]
   uint16_t* sIdx = (uint16_t*)(sCoef + (size_t)rows_max * 64);   // [rows_max / 4][64][4]
   // (no static __shared__ here: statics precede the dynamic region unpadded, 33 ints would leave every ds_read_b64 / b128 below
   // misaligned - replayed at 64 cycles per wave-instruction; measured: 143 instead of 46 ms per 256 systems of cfg 3)
@@ -804,6 +806,8 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
   typedef double v2d_t __attribute__((ext_vector_type(2)));   // (a native vector: a struct cannot be a tied asm operand)
 #define BIEM_TN_DECL(k) v2d_t tn##k = {0.0, 0.0};
   BIEM_TN_LIST(BIEM_TN_DECL)
+#define BIEM_TM_DECL(k) v2d_t tm##k = {0.0, 0.0};
+  BIEM_TN_LIST(BIEM_TM_DECL)                                 // (second combination of an iteration, NC = 2)
   // The prefetch loads are inline asm and their wait is the explicit one of BIEM_TN_CLAIM: hipcc's own wait for a VGPR load is a
   // vmcnt(0) wherever control flow joins, i.e. at the top of the loop, AFTER this combination's stores - every iteration would then
   // wait for the acknowledgement of its own stores (microseconds under a full HBM write queue, with the CU to itself).
@@ -811,19 +815,27 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(tn##k) : "v"(a_) : "memory"); }
 #define BIEM_TN_CLAIM(k) if (k < KT) asm volatile("s_waitcnt vmcnt(0)" : "+v"(tn##k) : : "memory");
 #define BIEM_TN_PUT(k) if (k < KT) { const int l = k * FILL_SYM_THREADS + tid; if (l < HR) sT[l] = make_double2(tn##k.x, tn##k.y); }
+#define BIEM_TM_LOAD(k) if (NC > 1 && k < KT) { const int l = k * FILL_SYM_THREADS + tid; const cplx* a_ = Tp_ + (l < HR ? l : HR - 1); \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(tm##k) : "v"(a_) : "memory"); }
+#define BIEM_TM_CLAIM(k) if (NC > 1 && k < KT) asm volatile("s_waitcnt vmcnt(0)" : "+v"(tm##k) : : "memory");
+#define BIEM_TM_PUT(k) if (NC > 1 && k < KT) { const int l = k * FILL_SYM_THREADS + tid; if (l < HR) sT[HR + l] = make_double2(tm##k.x, tm##k.y); }
   // a combination is (system s, class ci); its table is the one of the class's first pair (dup_bb: b << 16 | bp, the representative first)
   auto table_of = [&](int cb) -> const cplx* {
     const int s = cb / nrep, bb = dup_bb[dup_ptr[cb - s * nrep]];
     return T + ((size_t)s * B * B + (size_t)(bb >> 16) * B + (bb & 0xffff)) * HR;
   };
+  // iteration i of this workgroup takes the combinations comb and (NC = 2) comb + G, G = gridDim.y; the next one comb + NC G
+  const int G = gridDim.y;
   int comb = blockIdx.y;
   if (comb < ncomb) { const cplx* Tp_ = table_of(comb); BIEM_TN_LIST(BIEM_TN_LOAD) }
+  if (NC > 1 && comb + G < ncomb) { const cplx* Tp_ = table_of(comb + G); BIEM_TN_LIST(BIEM_TM_LOAD) }
   BIEM_TN_LIST(BIEM_TN_CLAIM)
+  BIEM_TN_LIST(BIEM_TM_CLAIM)
 #ifdef BIEM_FILL_TRACE
   unsigned long long ft_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ft_t = __builtin_amdgcn_s_memtime();
 #endif
-  for (; comb < ncomb; comb += gridDim.y) {
-    const int s = comb / nrep, ci = comb - s * nrep;
+  for (; comb < ncomb; comb += NC * G) {
+    const bool two = NC > 1 && comb + G < ncomb;           // (wave-uniform) a second combination in this iteration
     BIEM_FT(0)
     // Raw barriers with an LDS-only wait: __syncthreads() carries a workgroup-scope fence, which hipcc lowers to s_waitcnt vmcnt(0) -
     // every barrier would wait for the acknowledgement of the previous combination's global stores (nobody in the workgroup reads
@@ -831,10 +843,12 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
     lds_barrier();                                         // the previous combination's readers are done (also orders the chunk loads)
     BIEM_FT(1)
     BIEM_TN_LIST(BIEM_TN_PUT)
+    BIEM_TN_LIST(BIEM_TM_PUT)
     BIEM_FT(2)
     lds_barrier();
     BIEM_FT(4)
-    if (comb + (int)gridDim.y < ncomb) { const cplx* Tp_ = table_of(comb + (int)gridDim.y); BIEM_TN_LIST(BIEM_TN_LOAD) }   // lands while this combination is contracted
+    if (comb + NC * G < ncomb) { const cplx* Tp_ = table_of(comb + NC * G); BIEM_TN_LIST(BIEM_TN_LOAD) }   // lands while this iteration is contracted
+    if (NC > 1 && comb + (NC + 1) * G < ncomb) { const cplx* Tp_ = table_of(comb + (NC + 1) * G); BIEM_TN_LIST(BIEM_TM_LOAD) }
     // (a wave without unit pairs runs zero groups and joins the others at the claim of the prefetched registers below: every path
     // through the loop body must pass that point, or the compiler drains the memory queue again where the paths meet)
     const bool wave_on = wave * 64 < npr;
@@ -844,6 +858,7 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
     // the accumulators are handed over.
     const int ga = wave_on ? sW[2 * wave] >> 2 : 0, gb = wave_on ? sW[2 * wave + 1] >> 2 : 0, ge = wave_on ? sW[2 * wave + 2] >> 2 : 0;
     double ar = 0.0, ai = 0.0, xr = 0.0, xi = 0.0;        // running sums; (xr, xi) keeps list A's once list B has started
+    double br = 0.0, bi = 0.0, yr = 0.0, yi = 0.0;        // the same for the second combination
     if (ga < ge) {
       const double* cc = sCoef + lane;
       const uint2* ii = (const uint2*)sIdx + lane;
@@ -852,13 +867,21 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
       for (int g = ga; g < ge; ++g) {
         const int gn = g + 1 < ge ? g + 1 : g;             // (the last trip re-reads its own group: harmless)
         const cplx z0 = sT[pk.x & 0xffffu], z1 = sT[pk.x >> 16], z2 = sT[pk.y & 0xffffu], z3 = sT[pk.y >> 16];
+        cplx w0, w1, w2, w3;
+        if (NC > 1) { w0 = sT[HR + (pk.x & 0xffffu)]; w1 = sT[HR + (pk.x >> 16)]; w2 = sT[HR + (pk.y & 0xffffu)]; w3 = sT[HR + (pk.y >> 16)]; }
         const uint2 pkn = ii[(size_t)gn * 64];
         const double n0 = cc[(size_t)(4 * gn) * 64], n1 = cc[(size_t)(4 * gn + 1) * 64], n2 = cc[(size_t)(4 * gn + 2) * 64], n3 = cc[(size_t)(4 * gn + 3) * 64];
-        if (g == gb) { xr = ar; xi = ai; ar = 0.0; ai = 0.0; }
+        if (g == gb) { xr = ar; xi = ai; ar = 0.0; ai = 0.0; yr = br; yi = bi; br = 0.0; bi = 0.0; }
         ar = fma(c0, z0.x, ar); ai = fma(c0, z0.y, ai);
         ar = fma(c1, z1.x, ar); ai = fma(c1, z1.y, ai);
         ar = fma(c2v, z2.x, ar); ai = fma(c2v, z2.y, ai);
         ar = fma(c3, z3.x, ar); ai = fma(c3, z3.y, ai);
+        if (NC > 1) {
+          br = fma(c0, w0.x, br); bi = fma(c0, w0.y, bi);
+          br = fma(c1, w1.x, br); bi = fma(c1, w1.y, bi);
+          br = fma(c2v, w2.x, br); bi = fma(c2v, w2.y, bi);
+          br = fma(c3, w3.x, br); bi = fma(c3, w3.y, bi);
+        }
         pk = pkn; c0 = n0; c1 = n1; c2v = n2; c3 = n3;
       }
     }
@@ -866,12 +889,13 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
     // The prefetched table row is claimed HERE, before this combination's stores are issued: the wait then sees only the loads (issued
     // before the contraction) and the PREVIOUS combination's stores, which have had a whole iteration to drain.
     BIEM_TN_LIST(BIEM_TN_CLAIM)
+    BIEM_TN_LIST(BIEM_TM_CLAIM)
     if (!active) continue;
-    cplx RA, RB;
-    if (gb < ge) { RA = make_double2(xr, xi); RB = make_double2(ar, ai); }
-    else { RA = make_double2(ar, ai); RB = make_double2(0.0, 0.0); }
+    // the block of one combination from its two sums: phases, the 2 x 2 transform to real harmonics, q factors, stores
+    auto finish = [&](const cplx* sTc, int cb, cplx RA, cplx RB) {
+    const int s = cb / nrep, ci = cb - s * nrep;
     // entries of the 2 x 2 raw block: (h,h') = phase_A R_A, its conjugate entry conj(phase_A) R_A; (h,p') = phase_B R_B, (p,h') = conj(phase_B) R_B
-    cplx phA = sT[E + (selA >> 1)], phB = sT[E + (selB >> 1)];
+    cplx phA = sTc[E + (selA >> 1)], phB = sTc[E + (selB >> 1)];
     if (selA & 1u) phA.y = -phA.y;
     if (selB & 1u) phB.y = -phB.y;
     const cplx mA = cmul(RA, make_double2(phA.x, -phA.y));
@@ -886,7 +910,7 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
       const cplx a1c = make_double2((x10.x + x11.x) * q2, (x10.y + x11.y) * q2), d1 = make_double2((x11.x - x10.x) * q2, (x11.y - x10.y) * q2);
       x00 = a0c; x01 = make_double2(-d0.y, d0.x); x10 = a1c; x11 = make_double2(-d1.y, d1.x);
     }
-    const cplx scale = cmul(sT[E + NP + nrow], sT[E + NP + n_end + ncol]);
+    const cplx scale = cmul(sTc[E + NP + nrow], sTc[E + NP + n_end + ncol]);
     x00 = cmul(x00, scale); x01 = cmul(x01, scale); x10 = cmul(x10, scale); x11 = cmul(x11, scale);
     cplx* As = A + (size_t)s * sys_stride;
     const int e0 = dup_ptr[ci], e1 = dup_ptr[ci + 1];
@@ -909,6 +933,13 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
         if (r2) { mirror(row_s, col_c, x10); if (c2) mirror(row_s, col_s, x11); }
       }
     }
+    };
+    if (gb < ge) finish(sT, comb, make_double2(xr, xi), make_double2(ar, ai));
+    else finish(sT, comb, make_double2(ar, ai), make_double2(0.0, 0.0));
+    if (two) {
+      if (gb < ge) finish(sT + HR, comb + G, make_double2(yr, yi), make_double2(br, bi));
+      else finish(sT + HR, comb + G, make_double2(br, bi), make_double2(0.0, 0.0));
+    }
     BIEM_FT(6)
   }
 #ifdef BIEM_FILL_TRACE
@@ -919,6 +950,10 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
 #undef BIEM_TN_LOAD
 #undef BIEM_TN_PUT
 #undef BIEM_TN_CLAIM
+#undef BIEM_TM_DECL
+#undef BIEM_TM_LOAD
+#undef BIEM_TM_CLAIM
+#undef BIEM_TM_PUT
 }
 #ifdef BIEM_FILL_TRACE
 extern "C" int biem_debug_fill_trace(unsigned long long* out, int reset) {
@@ -1292,18 +1327,28 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
     if (gy > 65535) gy = 65535;
     const int HR = p->E + p->NP + 2 * p->n_end;
     const int kt_need = ((use_red ? HR : p->H2lin) + FILL_SYM_THREADS - 1) / FILL_SYM_THREADS;
-#define BIEM_LAUNCH_FILL_RED(KT)                                                                                                          \
+#define BIEM_LAUNCH_FILL_RED(KT, NC)                                                                                                      \
   {                                                                                                                                       \
-    BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_fill_red<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));                  \
-    hipLaunchKernelGGL(k_fill_red<KT>, dim3(nchunks, (unsigned)gy), dim3(FILL_SYM_THREADS), shm, st, H, U, HR, p->E, p->NP, p->n_end, B, nb, npairs, \
+    BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_fill_red<KT, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));              \
+    hipLaunchKernelGGL((k_fill_red<KT, NC>), dim3(nchunks, (unsigned)gy), dim3(FILL_SYM_THREADS), shm, st, H, U, HR, p->E, p->NP, p->n_end, B, nb, npairs, \
                        p->d_deg, p->d_units, p->d_spos, p->d_rchunk, p->d_rcrow, p->d_rwrow, p->rchunk_rows_max, p->d_rcoef, p->d_ridx,   \
                        p->d_rphsel, T, (cplx*)d_A, lda, sys_stride, classes);                                                             \
   }
     if (use_red) {
-      if (kt_need <= 1) BIEM_LAUNCH_FILL_RED(1)
-      else if (kt_need <= 2) BIEM_LAUNCH_FILL_RED(2)
-      else if (kt_need <= 4) BIEM_LAUNCH_FILL_RED(4)
-      else BIEM_LAUNCH_FILL_RED(8)
+      // two combinations per iteration (the plan reserves LDS for two table rows) unless BIEM_FILL_NC=1 (A / B runs)
+      const char* nce = getenv("BIEM_FILL_NC");
+      const bool nc2 = !(nce && nce[0] == '1');
+      if (nc2) {
+        if (kt_need <= 1) BIEM_LAUNCH_FILL_RED(1, 2)
+        else if (kt_need <= 2) BIEM_LAUNCH_FILL_RED(2, 2)
+        else if (kt_need <= 4) BIEM_LAUNCH_FILL_RED(4, 2)
+        else BIEM_LAUNCH_FILL_RED(8, 2)
+      } else {
+        if (kt_need <= 1) BIEM_LAUNCH_FILL_RED(1, 1)
+        else if (kt_need <= 2) BIEM_LAUNCH_FILL_RED(2, 1)
+        else if (kt_need <= 4) BIEM_LAUNCH_FILL_RED(4, 1)
+        else BIEM_LAUNCH_FILL_RED(8, 1)
+      }
     } else
 #define BIEM_LAUNCH_FILL_SYM(KT)                                                                                                          \
   {                                                                                                                                       \

@@ -425,7 +425,7 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
       // transposed, padded lists per wave of 64 unit pairs; chunks of at most 16 waves within the LDS budget
       p->rcoef.clear(); p->ridx.clear(); p->rchunk.assign(1, 0); p->rcrow.assign(1, 0); p->rwrow.clear(); p->rchunk_rows_max = 0;
       const long long total_pairs = lists ? (long long)U * U : 0;
-      const long long lds_budget = 156 * 1024 - (long long)(p->E + p->NP) * 16 - (long long)2 * n_end * 16 - 33 * 4 - 256;
+      const long long lds_budget = 156 * 1024 - 2 * ((long long)(p->E + p->NP) * 16 + (long long)2 * n_end * 16) - 33 * 4 - 256;   // two table rows (k_fill_red, NC = 2)
       const long long cap_rows = lds_budget > 0 ? lds_budget / (64 * 10) : 0;          // a row: 64 x (8-byte coefficient + 2-byte index)
       std::vector<int> wr(33, 0);
       long long crows = 0; int cw = 0;                     // rows / waves of the open chunk
