@@ -327,6 +327,31 @@ def test_batch_of_wavenumbers_matches_one_by_one(amd):
         assert np.max(np.abs(u[:, s] - uo) / np.abs(uo)) < 1e-10
 
 
+def test_resident_bytes_cap_of_the_default_chunk(amd, monkeypatch):
+    """BIEM_MAX_RESIDENT_BYTES bounds the workspace biem() takes when `chunk` is left to it (by default 85 % of the memory the process can
+    get): a cap of two systems' worth streams the batch through two resident matrices - same densities, bit for bit."""
+    from biem_helmholtz_sphere_amd import _biem as impl
+
+    c = amd.create_from_branching_types("ba")
+    cen = O.grid_centers(1, 3)
+    ks = np.linspace(0.5, 3.0, 5)
+    dirs = np.tile(np.array([[1.0], [0.0], [0.0]]), (1, 5))
+    uin, _ = amd.plane_wave(k=_dev(ks), direction=_dev(dirs))
+    kw = dict(centers=_dev(cen)[None], radii=_dev(np.ones(4))[None], k=_dev(ks), n_end=6, uin=uin)
+    ref = amd.biem(c, **kw).density
+    plan = impl._plan("ba", 6, torch.device("cuda", 0))
+    lib_ = impl.L.load()
+    per = int(lib_.biem_solve_workspace_bytes(plan.handle, 1, 4, 1, 1))
+    monkeypatch.setenv("BIEM_MAX_RESIDENT_BYTES", str(2 * per + per // 2))
+    peak0 = torch.cuda.max_memory_allocated()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    got = amd.biem(c, **kw).density
+    assert torch.equal(got, ref)
+    assert torch.cuda.max_memory_allocated() - base < 3 * per + (8 << 20), (torch.cuda.max_memory_allocated() - base, per)
+    del peak0
+
+
 def test_mfma_f64_rate_is_reported(lib):
     l, L = lib
     t = C.c_double()
