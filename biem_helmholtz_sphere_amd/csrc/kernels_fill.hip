@@ -409,9 +409,9 @@ static bool fill_sym_entry_fits(const biem_plan* p, size_t* shm_out) {
 
 // the reduced-table form (k_fill_red): reduced pair table + phases, q factors and the chunk's transposed lists in LDS
 static bool fill_red_fits(const biem_plan* p, size_t* shm_out) {
-  const size_t shm = (size_t)2 * (p->E + p->NP + 2 * p->n_end) * sizeof(cplx) + (size_t)p->rchunk_rows_max * 64 * 10 + 33 * 4 + 64;   // two table rows
+  const size_t shm = (size_t)p->red_nc * (p->E + p->NP + 2 * p->n_end) * sizeof(cplx) + (size_t)p->rchunk_rows_max * 64 * 10 + 33 * 4 + 64;
   if (shm_out) *shm_out = shm;
-  return p->red_lists_ok && shm <= 158 * 1024 && p->E + p->NP + 2 * p->n_end <= 8 * 1024;
+  return p->red_lists_ok && shm <= (size_t)(p->red_waves == 16 ? 158 : 79) * 1024 && p->E + p->NP + 2 * p->n_end <= 8 * 64 * p->red_waves;
 }
 
 // pair classes of the symmetric fill (k_pair_dedupe), behind the pair tables: nrep (+3 pad), rep_list[np], dup_ptr[np + 1], dup_bb[np]
@@ -775,14 +775,14 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
   // (no static __shared__ here: statics precede the dynamic region unpadded, 33 ints would leave every ds_read_b64 / b128 below
   // misaligned - replayed at 64 cycles per wave-instruction; measured: 143 instead of 46 ms per 256 systems of cfg 3)
   int* sW = (int*)(sIdx + (size_t)rows_max * 64);          // [33] row offsets of the waves' lists
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63, TH = blockDim.x;          // 1024 threads (one workgroup per CU) or 512 (two)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p0 = rchunk[blockIdx.x], p1 = rchunk[blockIdx.x + 1], npr = p1 - p0;
   const int r0 = rcrow[blockIdx.x], nrows = rcrow[blockIdx.x + 1] - r0;
   {
     const double* gc = rcoef + (size_t)r0 * 64;
     const uint16_t* gi = ridx + (size_t)r0 * 64;
-    for (int q = tid; q < nrows * 64; q += FILL_SYM_THREADS) { sCoef[q] = gc[q]; sIdx[q] = gi[q]; }
+    for (int q = tid; q < nrows * 64; q += TH) { sCoef[q] = gc[q]; sIdx[q] = gi[q]; }
     if (tid < 33) sW[tid] = rwrow[blockIdx.x * 33 + tid];
   }
   // this thread's unit pair (fixed for the whole kernel): slots, degrees, phase selectors and the offsets of its (up to) four
@@ -811,14 +811,14 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
   // The prefetch loads are inline asm and their wait is the explicit one of BIEM_TN_CLAIM: hipcc's own wait for a VGPR load is a
   // vmcnt(0) wherever control flow joins, i.e. at the top of the loop, AFTER this combination's stores - every iteration would then
   // wait for the acknowledgement of its own stores (microseconds under a full HBM write queue, with the CU to itself).
-#define BIEM_TN_LOAD(k) if (k < KT) { const int l = k * FILL_SYM_THREADS + tid; const cplx* a_ = Tp_ + (l < HR ? l : HR - 1); \
+#define BIEM_TN_LOAD(k) if (k < KT) { const int l = k * TH + tid; const cplx* a_ = Tp_ + (l < HR ? l : HR - 1); \
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(tn##k) : "v"(a_) : "memory"); }
 #define BIEM_TN_CLAIM(k) if (k < KT) asm volatile("s_waitcnt vmcnt(0)" : "+v"(tn##k) : : "memory");
-#define BIEM_TN_PUT(k) if (k < KT) { const int l = k * FILL_SYM_THREADS + tid; if (l < HR) sT[l] = make_double2(tn##k.x, tn##k.y); }
-#define BIEM_TM_LOAD(k) if (NC > 1 && k < KT) { const int l = k * FILL_SYM_THREADS + tid; const cplx* a_ = Tp_ + (l < HR ? l : HR - 1); \
+#define BIEM_TN_PUT(k) if (k < KT) { const int l = k * TH + tid; if (l < HR) sT[l] = make_double2(tn##k.x, tn##k.y); }
+#define BIEM_TM_LOAD(k) if (NC > 1 && k < KT) { const int l = k * TH + tid; const cplx* a_ = Tp_ + (l < HR ? l : HR - 1); \
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(tm##k) : "v"(a_) : "memory"); }
 #define BIEM_TM_CLAIM(k) if (NC > 1 && k < KT) asm volatile("s_waitcnt vmcnt(0)" : "+v"(tm##k) : : "memory");
-#define BIEM_TM_PUT(k) if (NC > 1 && k < KT) { const int l = k * FILL_SYM_THREADS + tid; if (l < HR) sT[HR + l] = make_double2(tm##k.x, tm##k.y); }
+#define BIEM_TM_PUT(k) if (NC > 1 && k < KT) { const int l = k * TH + tid; if (l < HR) sT[HR + l] = make_double2(tm##k.x, tm##k.y); }
   // a combination is (system s, class ci); its table is the one of the class's first pair (dup_bb: b << 16 | bp, the representative first)
   auto table_of = [&](int cb) -> const cplx* {
     const int s = cb / nrep, bb = dup_bb[dup_ptr[cb - s * nrep]];
@@ -1326,18 +1326,18 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
     if (gy > ncomb) gy = ncomb;
     if (gy > 65535) gy = 65535;
     const int HR = p->E + p->NP + 2 * p->n_end;
-    const int kt_need = ((use_red ? HR : p->H2lin) + FILL_SYM_THREADS - 1) / FILL_SYM_THREADS;
+    const int red_threads = 64 * p->red_waves;
+    const int kt_need = use_red ? (HR + red_threads - 1) / red_threads : (p->H2lin + FILL_SYM_THREADS - 1) / FILL_SYM_THREADS;
 #define BIEM_LAUNCH_FILL_RED(KT, NC)                                                                                                      \
   {                                                                                                                                       \
     BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_fill_red<KT, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));              \
-    hipLaunchKernelGGL((k_fill_red<KT, NC>), dim3(nchunks, (unsigned)gy), dim3(FILL_SYM_THREADS), shm, st, H, U, HR, p->E, p->NP, p->n_end, B, nb, npairs, \
+    hipLaunchKernelGGL((k_fill_red<KT, NC>), dim3(nchunks, (unsigned)gy), dim3(red_threads), shm, st, H, U, HR, p->E, p->NP, p->n_end, B, nb, npairs, \
                        p->d_deg, p->d_units, p->d_spos, p->d_rchunk, p->d_rcrow, p->d_rwrow, p->rchunk_rows_max, p->d_rcoef, p->d_ridx,   \
                        p->d_rphsel, T, (cplx*)d_A, lda, sys_stride, classes);                                                             \
   }
     if (use_red) {
-      // two combinations per iteration (the plan reserves LDS for two table rows) unless BIEM_FILL_NC=1 (A / B runs)
-      const char* nce = getenv("BIEM_FILL_NC");
-      const bool nc2 = !(nce && nce[0] == '1');
+      // two combinations per iteration (the plan reserves LDS for two table rows) unless BIEM_FILL_NC=1 at plan build (A / B runs)
+      const bool nc2 = p->red_nc == 2;
       if (nc2) {
         if (kt_need <= 1) BIEM_LAUNCH_FILL_RED(1, 2)
         else if (kt_need <= 2) BIEM_LAUNCH_FILL_RED(2, 2)

@@ -425,7 +425,10 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
       // transposed, padded lists per wave of 64 unit pairs; chunks of at most 16 waves within the LDS budget
       p->rcoef.clear(); p->ridx.clear(); p->rchunk.assign(1, 0); p->rcrow.assign(1, 0); p->rwrow.clear(); p->rchunk_rows_max = 0;
       const long long total_pairs = lists ? (long long)U * U : 0;
-      const long long lds_budget = 156 * 1024 - 2 * ((long long)(p->E + p->NP) * 16 + (long long)2 * n_end * 16) - 33 * 4 - 256;   // two table rows (k_fill_red, NC = 2)
+      { const char* ew = getenv("BIEM_FILL_RED_WAVES"); p->red_waves = (ew && atoi(ew) == 8) ? 8 : 16;
+        const char* en = getenv("BIEM_FILL_NC"); p->red_nc = (en && en[0] == '1') ? 1 : 2; }
+      // LDS of a workgroup: 16 waves - the CU to itself; 8 waves - two workgroups per CU (their phases overlap); red_nc table rows
+      const long long lds_budget = (p->red_waves == 16 ? 156 : 76) * 1024 - p->red_nc * ((long long)(p->E + p->NP) * 16 + (long long)2 * n_end * 16) - 33 * 4 - 256;
       const long long cap_rows = lds_budget > 0 ? lds_budget / (64 * 10) : 0;          // a row: 64 x (8-byte coefficient + 2-byte index)
       std::vector<int> wr(33, 0);
       long long crows = 0; int cw = 0;                     // rows / waves of the open chunk
@@ -456,7 +459,7 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
         LA = (LA + 3) & ~3u; LB = (LB + 3) & ~3u;           // the kernel walks the lists in groups of four rows
         if (!rok) break;
         if ((long long)(LA + LB) > cap_rows) { rok = false; break; }                    // one wave alone exceeds the LDS budget
-        if (cw == 16 || crows + LA + LB > cap_rows) close_chunk(w0);
+        if (cw == p->red_waves || crows + LA + LB > cap_rows) close_chunk(w0);
         wr[2 * cw] = (int)crows; wr[2 * cw + 1] = (int)(crows + LA); wr[2 * cw + 2] = (int)(crows + LA + LB);
         for (int pass = 0; pass < 2; ++pass) {
           const uint32_t L = pass ? LB : LA;

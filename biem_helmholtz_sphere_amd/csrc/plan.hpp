@@ -65,6 +65,7 @@ struct biem_plan {
   // lane (ridx[(group * 64 + lane) * 4 + k]: one 8-byte read per lane and group).  Chunk c = unit pairs [rchunk[c], rchunk[c+1]) (at most 1024 = 16 waves), its rows
   // [rcrow[c], rcrow[c+1]); rwrow[c * 33 + 2 w + {0, 1, 2}] = first row of wave w's list A, of its list B, end (relative to the chunk).
   bool red_lists_ok = false;
+  int red_waves = 16, red_nc = 2;           // workgroup of k_fill_red (waves) and combinations per iteration the chunks were cut for (experiments: BIEM_FILL_RED_WAVES=8, BIEM_FILL_NC=1 at plan build)
   std::vector<double> rcoef;                // [rows][64]
   std::vector<uint16_t> ridx;               // [rows][64] indices e into T'
   std::vector<uint16_t> rphsel;             // [U U][2]: phase selector of list A, of list B: 2 * phase id + (1: conjugate phase)

@@ -39,6 +39,20 @@ copy_line("bench_cfg3_lu.json", "bench_cfg3_256sys_lu_only.json")
 copy_line("bench_2ranks_weak_shared_gpu.json", "bench_2ranks_weak_shared_gpu.json")
 copy_line("bench_2ranks_strong_shared_gpu.json", "bench_2ranks_strong_shared_gpu.json")
 copy_line("bench_rccl_1rank.json", "bench_rccl_1rank.json")
+copy_line("bench_rccl_1rank_cfg5.json", "bench_rccl_1rank_cfg5.json")
+copy_line("bench_cfg3_no_pair_classes.json", "bench_cfg3_256sys_no_pair_classes.json")
+for c in (4, 5):
+    copy_line(f"bench_cfg{c}_no_pair_classes.json", f"bench_cfg{c}_no_pair_classes.json")
+rows_ = []
+for sz in (32, 64, 128):
+    jj = copy_line(f"bench_cfg3_{sz}sys.json", f"bench_cfg3_{sz}sys.json")
+    if jj:
+        rows_.append((sz, jj["value"], jj["ms_per_step"]))
+if rows_ and main:
+    with open(os.path.join(out, P + "throughput_vs_systems_per_gpu.txt"), "w") as f_:
+        f_.write("cfg 3 on one GPU at the per-rank batch of the strong-scaling split (8 / 4 / 2 / 1 GPUs): systems per step, systems/s, ms per step, share of the full-batch rate\n")
+        for sz, v, ms_ in rows_ + [(256, main["value"], main["ms_per_step"])]:
+            f_.write(f"{sz:4d} {v:8.1f} {ms_:9.1f} {100 * v / main['value']:6.1f} %\n")
 
 ks = os.path.join(ev, "kt", "p_kernel_stats.csv")
 if os.path.exists(ks):
@@ -66,6 +80,9 @@ if os.path.exists(ps):
     nsys = 8
     fetch, nl = counter("k_gemm3m_pipe<256>", "FETCH_SIZE")
     write, _ = counter("k_gemm3m_pipe<256>", "WRITE_SIZE")
+    keep = os.path.join(out, P + "gemm_traffic.json")
+    if os.path.exists(keep) and json.load(open(keep)).get("systems_per_launch") == 256:
+        fetch = None          # the traffic file measured at the timed launch shape (256 systems) stays
     if fetch and write:
         tiles = sum(t * (t + 1) // 2 for t in range(96, 0, -4))          # upper-triangle tiles of the 24 K = 256 updates at N = 6400
         alg = tiles * 64 * 64 * 16 * 2 / nl                                 # C read + written once, per launch per system (average)
@@ -82,12 +99,12 @@ if os.path.exists(ps):
             j["note_lu"] = "general (square) tile order of the pivoted LU path, unchanged since round 1 (profiles/r01_v8_gemm3m_pipe_pmc.txt)"
         json.dump(j, open(os.path.join(out, P + "gemm_traffic.json"), "w"), indent=1)
         print("gemm traffic ratio", j["bytes_per_launch_per_system"] / alg)
-    fw, _ = counter("k_fill_sym<", "WRITE_SIZE")
-    ff, _ = counter("k_fill_sym<", "FETCH_SIZE")
+    fw, _ = counter("k_fill_red<", "WRITE_SIZE")
+    ff, _ = counter("k_fill_red<", "FETCH_SIZE")
     dw, _ = counter("k_fill_sym_diag", "WRITE_SIZE")
     pw, _ = counter("k_pair_tables", "WRITE_SIZE")
     if fw:
-        j = {"kernels": "k_pair_tables + k_fill_sym + k_fill_sym_diag (symmetric fill of the default path)",
+        j = {"kernels": "k_pair_tables + k_fill_red + k_fill_sym_diag (symmetric fill of the default path)",
              "source": f"rocprofv3 --pmc passes at {nsys} systems, profiles/{P}pmc_summary.txt",
              "write_bytes_per_system": (fw + (dw or 0) + (pw or 0)) * 1024 / nsys, "fetch_bytes_per_system_corrected": 2 * (ff or 0) * 1024 / nsys,
              "bytes_per_system": ((fw + (dw or 0) + (pw or 0)) + 2 * (ff or 0)) * 1024 / nsys,
