@@ -408,7 +408,8 @@ def main() -> int:
         traffic_src = (f"profiles/{tname}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs of this bench.py; FETCH_SIZE doubled per the gfx950 "
                        f"correction) at {tj.get('systems_per_launch', 8)} systems per launch"
                        + (" = this run's launch shape" if same else f", scaled to {per} systems per launch") + "; counters cannot be read inside the timed run")
-    fj = profile_json("r02_fill_traffic.json")
+    fname = next((n for n in ("r03_fill_traffic.json", "r02_fill_traffic.json") if profile_json(n)), None)
+    fj = profile_json(fname) if fname else None
     fill_traffic = fj["bytes_per_system"] * nloc if fj and cfg == 3 else None
 
     cen_ = np.asarray(w["centers"], dtype=np.float64)
@@ -456,7 +457,7 @@ def main() -> int:
         # contracted once and stored to every pair of the class - all radii and Robin coefficients are equal in these workloads)
         "fill": {"bound": "hbm", "pair_classes": pair_classes, "achieved": fill_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fill_gbs / HBM_PEAK_GBS if fill_gbs else None,
                  "bytes_counted": "what the factorisation reads: upper triangle + diagonal 64 x 64 tiles of the symmetric form (default path), or 16 N^2 per system (BIEM_SOLVER=lu)",
-                 "traffic": fill_traffic, "traffic_source": "profiles/r02_fill_traffic.json (rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE), scaled" if fill_traffic else None},
+                 "traffic": fill_traffic, "traffic_source": f"profiles/{fname} (rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE at 8 systems, pair classes on), scaled to {nloc} systems" if fill_traffic else None},
         "stage_ms_per_step": {n: m / args.steps for n, m in zip(CLASSES, ms)},
         "single_system_ms": single_ms,
         "marshalling_ms": marshalling_ms, "rccl_ranks": rccl_ranks,
