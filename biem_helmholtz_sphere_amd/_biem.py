@@ -615,7 +615,7 @@ def biem(
 
     Solver: the reference passes every system to a general dense solve (``_biem.py:797``).  Here the system is first brought
     to its complex-symmetric form (real harmonics, symmetric scaling) and factored as U^T U (Cholesky-type, no conjugation)
-    without interchanges - half the flops; a system in which a multiplier would exceed 10, or whose factor grew by more than
+    without interchanges - half the flops; a system in which a multiplier would exceed 100, or whose factor grew by more than
     200, is solved by the pivoted LU instead (``BIEM_SOLVER=lu`` in the environment: pivoted LU for all).  Both give the
     reference's ``density`` to rounding.
     """
