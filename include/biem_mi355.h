@@ -164,7 +164,7 @@ int biem_ldlt_factor(int nb, int n_pad, double* d_A, long long lda, long long sy
 /* Complex-SYMMETRIC systems (A = A^T, not Hermitian): A = L D L^T with the diagonal as pivots, no interchanges.  Same layout,
  * workspace and kernels as biem_lu_factor_solve; a panel's U rows are its transposed multipliers and the K = 256 updates run
  * over the lower triangle of tiles only (half the flops).  Only the lower triangle (and the diagonal 64 x 64 blocks) of A is
- * read.  d_info[s] = -(row+1), `row` = first row of the 64-column panel in which a diagonal entry was below 0.1 x the largest
+ * read.  d_info[s] = -(row+1), `row` = first row of the 64-column panel in which a diagonal entry was below 0.01 x the largest
  * entry of its (updated) column, i.e. a multiplier exceeded 100 (partial pivoting guarantees 1; 10 until round 2; or NaN);
  * d_info[s] = -(Npad+1): a-posteriori growth check failed, max |U| > 200 max |A| (|.| = |re| + |im|, A = the part read) or a
  * non-finite entry in U: the result of that system is not to be trusted and the caller re-solves it with biem_lu_factor_solve. */
