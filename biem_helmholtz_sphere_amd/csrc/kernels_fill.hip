@@ -1322,6 +1322,24 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
     }
     // enough workgroups to fill the chip a few times over, each with a long loop over combinations
     long long gy = (8 * 256 + nchunks - 1) / nchunks;
+    if (use_red && p->red_waves == 16) {
+      // one workgroup per CU at a time (its lists take the CU's LDS): the grid runs in rounds of 256 workgroups of about equal work, so a
+      // grid of 8.1 rounds costs 9.  Among 6 .. 10 rounds' worth of workgroups take the count that wastes least of its last round
+      // (cfg 3: 77 chunks x 27 = 8.12 rounds -> x 26 = 7.82: -10 % fill time)
+      static int ncu_of[64] = {0};               // CUs per device, queried once
+      int devid = 0, ncu = 256;
+      if (hipGetDevice(&devid) == hipSuccess && devid >= 0 && devid < 64) {
+        if (ncu_of[devid] == 0) { int v = 0; ncu_of[devid] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, devid) == hipSuccess && v > 0) ? v : 256; }
+        ncu = ncu_of[devid];
+      }
+      double best = 1e30;
+      for (long long g = (6LL * ncu + nchunks - 1) / nchunks; g <= (10LL * ncu) / nchunks + 1; ++g) {
+        if (g < 1) continue;
+        const double wgs = (double)nchunks * g, rounds = ceil(wgs / ncu);
+        const double waste = rounds * ncu / wgs;
+        if (waste < best - 1e-9 || (waste < best + 1e-9 && g > gy)) { best = waste; gy = g; }
+      }
+    }
     if (gy < 1) gy = 1;
     if (gy > ncomb) gy = ncomb;
     if (gy > 65535) gy = 65535;
