@@ -136,8 +136,8 @@ __global__ void __launch_bounds__(256) k_uscat(int tree, int d, int H, int n_end
 }
 
 // ---------------------------------------------------------------------------------------------
-// Near field of kind = "outer" and the far field, trees a (2-D), ba (3-D; bpa is ba in permuted axes) and bba (4-D; bpbpa
-// likewise): ONE POINT PER LANE.
+// Near field (both kinds) and the far field, trees a (2-D), ba (3-D; bpa is ba in permuted axes), bba (4-D; bpbpa likewise) and
+// caa: ONE POINT PER LANE.
 // The generic kernel above spends one workgroup per (point, system), evaluates every harmonic from scratch (an O(n) Legendre
 // recurrence and a sin / cos per harmonic) and leaves 63 lanes idle while lane 0 runs the radial recurrences: 2.0e6
 // point-systems/s at cfg 3 (16 balls, H = 400) - the 100 x 100 plot grid of the reference's second hot loop took as long as the
@@ -152,7 +152,11 @@ __global__ void __launch_bounds__(256) k_uscat(int tree, int d, int H, int n_end
 constexpr int kFastNendMax3 = 48;          // LDS: 2 n_end^2 doubles of recurrence coefficients + n_end^2 complex of c
 constexpr int kFastNendMax2 = kMaxRadU;    // 2-D: 2 n_end - 1 complex of c
 constexpr int kFastNendMax4 = 14;          // 4-D (bba): c in a dense [n][l][m] store, n_end^2 (2 n_end - 1) complex = 85 KB at 14
-template <int TREE, bool FAR>
+constexpr int kFastNendMaxCaa = 12;        // 4-D (caa): c in a dense [n][m1][m2] store, n_end (2 n_end - 1)^2 complex = 101 KB at 12
+// INNER (kind = "inner", near field): the radial factor is the regular function j_n(k r), whose upward recurrence is unstable
+// for n > |k r|: each lane computes j_0 .. j_{n_end-1} once per ball by the backward recurrence of radial_jh into its own LDS row
+// (64-thread workgroups; odd row stride: conflict-free 16-byte reads) and the harmonic loops read it by degree.
+template <int TREE, bool FAR, bool INNER>
 __global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, const int* __restrict__ labels, int nb, int B, int P,
                                                      const cplx* __restrict__ k, const double* __restrict__ centers,
                                                      const double* __restrict__ radii, int geom_batched, const cplx* __restrict__ c,
@@ -166,12 +170,22 @@ __global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, con
   double* ga = cmm + (LEG ? ((n_end + 1) & ~1) : 0);              // bba: Gegenbauer a_q of order lam = l + 1 at [l * n_end + q]
   double* gia = ga + (TREE == TREE_BBA ? n_end * n_end : 0);       //      1 / a_q
   double* g0 = gia + (TREE == TREE_BBA ? n_end * n_end : 0);       //      p_0 = 1 / sqrt(h_0(l))
-  cplx* sC = (cplx*)(g0 + (TREE == TREE_BBA ? ((n_end + 1) & ~1) : 0));
-  const int s = blockIdx.y, tid = threadIdx.x;
-  const int p = blockIdx.x * 256 + tid, pc = p < P ? p : P - 1;
+  // caa: the Jacobi recurrence p_{m+1} = (jA x + jB) p_m - jC p_{m-1} of cbar_single and its norm, at [(a * n_end + b) * K2 + m]
+  const int K2 = (n_end + 1) / 2, ncaa = TREE == TREE_CAA ? n_end * n_end * K2 : 0;
+  double* jA = g0 + (TREE == TREE_BBA ? ((n_end + 1) & ~1) : 0);
+  double* jB = jA + ncaa;
+  double* jC = jB + ncaa;
+  double* jN = jC + ncaa;
+  cplx* sC = (cplx*)(jN + ncaa);
+  const int ms = 2 * n_end - 1;
+  const int nC = TREE == TREE_BA ? n_end * n_end : TREE == TREE_BBA ? n_end * n_end * ms : TREE == TREE_CAA ? n_end * ms * ms : ms;
+  const int js = (n_end + 2) | 1;           // INNER: row stride of the per-lane j_n store (radial_jh wants n_end + 1 slots at d = 4)
+  const int s = blockIdx.y, tid = threadIdx.x, T = blockDim.x;
+  cplx* sJl = sC + nC + (size_t)tid * js;
+  const int p = blockIdx.x * T + tid, pc = p < P ? p : P - 1;
   const bool per_ball = (flags & BIEM_USCAT_PER_BALL) != 0, pb = (flags & BIEM_USCAT_POINTS_BATCHED) != 0;
   if (LEG) {
-    for (int e = tid; e < n_end * n_end; e += 256) {
+    for (int e = tid; e < n_end * n_end; e += T) {
       const int q = e / n_end, m = e - q * n_end;
       double a = 0.0, b = 0.0;
       if (q > m) {
@@ -180,16 +194,31 @@ __global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, con
       }
       ra[e] = a; rb[e] = b;
     }
-    for (int m = tid; m < n_end; m += 256) cmm[m] = m == 0 ? 0.0 : sqrt((double)(2 * m + 1) / (double)(2 * m));
+    for (int m = tid; m < n_end; m += T) cmm[m] = m == 0 ? 0.0 : sqrt((double)(2 * m + 1) / (double)(2 * m));
+  }
+  if (TREE == TREE_CAA) {
+    for (int e = tid; e < ncaa; e += T) {
+      const int a = e / (n_end * K2), b = (e / K2) % n_end, m = e % K2;
+      const double al = (double)b, be = (double)a;            // Jacobi P^{(alpha = b, beta = a)}
+      double A, Bc, C;
+      if (m == 0) { A = 0.5 * (al + be + 2.0); Bc = (al + 1.0) - A; C = 0.0; }
+      else {
+        const double t = 2.0 * m + al + be, den = 2.0 * (m + 1.0) * (m + al + be + 1.0) * t;
+        A = (t + 1.0) * (t + 2.0) * t / den; Bc = (t + 1.0) * (al * al - be * be) / den; C = 2.0 * (m + al) * (m + be) * (t + 2.0) / den;
+      }
+      double nr = 2.0 * (2.0 * m + a + b + 1.0);
+      for (int i = 1; i <= a; ++i) nr *= (double)(m + b + i) / (double)(m + i);
+      jA[e] = A; jB[e] = Bc; jC[e] = C; jN[e] = sqrt(nr);
+    }
   }
   if (TREE == TREE_BBA) {                   // the coefficients of gbar_single
-    for (int e = tid; e < n_end * n_end; e += 256) {
+    for (int e = tid; e < n_end * n_end; e += T) {
       const int l = e / n_end, q = e - l * n_end;
       const double lam = (double)(l + 1);
       const double aq = q == 0 ? 1.0 : 0.5 * sqrt((double)q * ((double)q + 2.0 * lam - 1.0) / (((double)q + lam - 1.0) * ((double)q + lam)));
       ga[e] = q == 0 ? 0.0 : aq; gia[e] = 1.0 / aq;
     }
-    for (int l = tid; l < n_end; l += 256) {
+    for (int l = tid; l < n_end; l += T) {
       double h0 = 0.5 * kPi;
       for (int i = 1; i <= l; ++i) h0 *= ((double)i + 0.5) / ((double)i + 1.0);
       g0[l] = 1.0 / sqrt(h0);
@@ -204,10 +233,11 @@ __global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, con
   for (int b = 0; b < B; ++b) {
     __syncthreads();                       // the previous ball's coefficients are no longer read (and the tables are written)
     const cplx* cs = c + ((size_t)s * B + b) * H;
-    for (int h = tid; h < H; h += 256) {
+    for (int h = tid; h < H; h += T) {
       int pos;
       if (TREE == TREE_BA) { const int n = labels[3 * h], m = labels[3 * h + 1]; pos = n * n + n + m; }
       else if (TREE == TREE_BBA) pos = (labels[3 * h] * n_end + labels[3 * h + 1]) * (2 * n_end - 1) + labels[3 * h + 2] + n_end - 1;
+      else if (TREE == TREE_CAA) pos = (labels[3 * h] * ms + labels[3 * h + 1] + n_end - 1) * ms + labels[3 * h + 2] + n_end - 1;
       else pos = labels[3 * h] + n_end - 1;
       sC[pos] = cs[h];
     }
@@ -217,11 +247,17 @@ __global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, con
     double u[4] = {0.0, 0.0, 0.0, 0.0}, r2 = 0.0;
     for (int i = 0; i < d; ++i) { u[i] = x[i] - cb[i]; r2 += u[i] * u[i]; }
     const double r = sqrt(r2);
-    if (!FAR && r < rho) bad = true;
+    if (!FAR && (INNER ? r > rho : r < rho)) bad = true;
     // h_0, h_1 at k r (r = 0 only inside a ball: the value is discarded).  Far field: the radial factor is (-i)^n, i.e. the
     // "recurrence" h_{n+1} = -i h_n from h_0 = 1 (advance() below)
     cplx h0 = make_double2(1.0, 0.0), h1 = make_double2(0.0, -1.0), ix = make_double2(0.0, 0.0);
-    if (!FAR) {
+    if (INNER) {
+      if (r > 0.0) radial_jh(d, n_end - 1, cscale(kk, r), (zc*)sJl, nullptr);
+      else {                                // centre of the ball: z_n(0) = delta_{n0} sqrt(pi/2) 2^{1-d/2} / Gamma(d/2)
+        const double z0 = d == 2 ? kSqrtHalfPi : d == 3 ? 1.0 : 0.5 * kSqrtHalfPi;
+        for (int n = 0; n < n_end; ++n) sJl[n] = make_double2(n == 0 ? z0 : 0.0, 0.0);
+      }
+    } else if (!FAR) {
       zc J2[4], H2[4];
       radial_jh(d, 1, cscale(kk, r > 0.0 ? r : rho), J2, H2);
       h0 = H2[0]; h1 = H2[1];
@@ -232,6 +268,7 @@ __global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, con
       if (FAR) return make_double2(hcur.y, -hcur.x);
       return csub(cmul(cscale(ix, two_q + dd2), hcur), hprev);
     };
+    auto radial = [&](int n, const cplx& hup) -> cplx { if (INNER) return sJl[n]; return hup; };   // the radial factor of degree n
     double ar = 0.0, ai = 0.0;
     if (TREE == TREE_A) {
       // Y_m = e^{i m theta} / sqrt(2 pi); degree n = |m|
@@ -242,7 +279,8 @@ __global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, con
         const cplx cp = sC[n_end - 1 + n];
         cplx t = make_double2(cp.x * ex - cp.y * ey, cp.x * ey + cp.y * ex);
         if (n > 0) { const cplx cn = sC[n_end - 1 - n]; t.x += cn.x * ex + cn.y * ey; t.y += cn.y * ex - cn.x * ey; }
-        ar += hp.x * t.x - hp.y * t.y; ai += hp.x * t.y + hp.y * t.x;
+        const cplx hv = radial(n, hp);
+        ar += hv.x * t.x - hv.y * t.y; ai += hv.x * t.y + hv.y * t.x;
         const cplx hn = advance(hp, hc, 2.0 * n + 2.0);
         hp = hc; hc = hn;
         const double nx = ex * e1x - ey * e1y; ey = ex * e1y + ey * e1x; ex = nx;
@@ -273,7 +311,8 @@ __global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, con
           const double alm = sl * p1;
           for (int n = l; n < n_end; ++n) {
             const double amp = alm * gp1;
-            const double wr = hp.x * amp, wi = hp.y * amp;
+            const cplx hv = radial(n, hp);
+            const double wr = hv.x * amp, wi = hv.y * amp;
             const cplx* cc = sC + (n * n_end + l) * mstride + n_end - 1;
             const cplx cp = cc[m];
             sr += wr * cp.x - wi * cp.y; si += wr * cp.y + wi * cp.x;
@@ -298,6 +337,62 @@ __global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, con
         ar += sr * ex - si * ey + qr * ex + qi * ey;
         ai += sr * ey + si * ex + qi * ex - qr * ey;
       }
+    } else if (TREE == TREE_CAA) {
+      // Y_{n m1 m2} = cos^a sin^b Pbar_k^{(b,a)}(cos 2 t0) e^{i (m1 t1 + m2 t2)} / (2 pi), a = |m1|, b = |m2|, n = a + b + 2 k: the
+      // Jacobi recurrence runs along k inside (a, b); the four sign combinations share it and the radial factor
+      const double r01 = sqrt(u[0] * u[0] + u[1] * u[1]), r23 = sqrt(u[2] * u[2] + u[3] * u[3]);
+      const double c0 = r > 0.0 ? r01 / r : 1.0, s0 = r > 0.0 ? r23 / r : 0.0, xx = c0 * c0 - s0 * s0;
+      const double e1x = r01 > 0.0 ? u[0] / r01 : 1.0, e1y = r01 > 0.0 ? u[1] / r01 : 0.0;
+      const double e2x = r23 > 0.0 ? u[2] / r23 : 1.0, e2y = r23 > 0.0 ? u[3] / r23 : 0.0;
+      double ca = 1.0, eax = 1.0, eay = 0.0;
+      cplx ha = h0, ha1 = h1;              // h_a, h_{a+1}
+      for (int a = 0; a < n_end; ++a) {
+        if (a > 0) {
+          ca *= c0;
+          const cplx hn = advance(ha, ha1, 2.0 * a);
+          ha = ha1; ha1 = hn;
+          const double nx = eax * e1x - eay * e1y; eay = eax * e1y + eay * e1x; eax = nx;
+        }
+        double sb = 1.0, ebx = 1.0, eby = 0.0;
+        cplx hb = ha, hb1 = ha1;           // h_{a+b}, h_{a+b+1}
+        for (int b = 0; a + b < n_end; ++b) {
+          if (b > 0) {
+            sb *= s0;
+            const cplx hn = advance(hb, hb1, 2.0 * (a + b));
+            hb = hb1; hb1 = hn;
+            const double nx = ebx * e2x - eby * e2y; eby = ebx * e2y + eby * e2x; ebx = nx;
+          }
+          const int tb = (a * n_end + b) * K2;
+          const double amp0 = ca * sb;
+          double p0 = 0.0, p1 = 1.0;
+          cplx hp = hb, hc = hb1;
+          double ppr = 0.0, ppi = 0.0, mpr = 0.0, mpi = 0.0, pmr = 0.0, pmi = 0.0, mmr = 0.0, mmi = 0.0;   // sums of the (+-a, +-b) coefficients
+          for (int kq = 0, n = a + b; n < n_end; ++kq, n += 2) {
+            const cplx hv = radial(n, hp);
+            const double amp = amp0 * jN[tb + kq] * p1;
+            const double wr = hv.x * amp, wi = hv.y * amp;
+            const cplx* cc = sC + (n * ms + n_end - 1) * ms + n_end - 1;
+            { const cplx cv = cc[a * ms + b]; ppr += wr * cv.x - wi * cv.y; ppi += wr * cv.y + wi * cv.x; }
+            if (a > 0) { const cplx cv = cc[-a * ms + b]; mpr += wr * cv.x - wi * cv.y; mpi += wr * cv.y + wi * cv.x; }
+            if (b > 0) { const cplx cv = cc[a * ms - b]; pmr += wr * cv.x - wi * cv.y; pmi += wr * cv.y + wi * cv.x; }
+            if (a > 0 && b > 0) { const cplx cv = cc[-a * ms - b]; mmr += wr * cv.x - wi * cv.y; mmi += wr * cv.y + wi * cv.x; }
+            if (n + 2 < n_end) {
+              const double p2 = (jA[tb + kq] * xx + jB[tb + kq]) * p1 - jC[tb + kq] * p0;
+              p0 = p1; p1 = p2;
+              cplx hn = advance(hp, hc, 2.0 * (n + 1));
+              hp = hc; hc = hn;
+              hn = advance(hp, hc, 2.0 * (n + 2));
+              hp = hc; hc = hn;
+            }
+          }
+          // e^{i (+-a t1 +- b t2)}
+          const double fx = eax * ebx - eay * eby, fy = eax * eby + eay * ebx;     // e^{i (a t1 + b t2)}
+          const double gx = eax * ebx + eay * eby, gy = eax * eby - eay * ebx;     // e^{i (-a t1 + b t2)}
+          ar += ppr * fx - ppi * fy + mmr * fx + mmi * fy + mpr * gx - mpi * gy + pmr * gx + pmi * gy;
+          ai += ppr * fy + ppi * fx + mmi * fx - mmr * fy + mpr * gy + mpi * gx + pmi * gx - pmr * gy;
+        }
+      }
+      ar *= kInvSqrt2Pi; ai *= kInvSqrt2Pi;   // (the second 1 / sqrt(2 pi) below)
     } else {
       const double rxy = sqrt(u[1] * u[1] + u[2] * u[2]);
       const double c0 = r > 0.0 ? u[0] / r : 1.0, s0 = r > 0.0 ? rxy / r : 0.0;
@@ -317,7 +412,8 @@ __global__ void __launch_bounds__(256) k_uscat_fast(int d, int H, int n_end, con
         double qr = 0.0, qi = 0.0;
         for (int n = m; n < n_end; ++n) {
           const cplx cp = sC[n * n + n + m];
-          const double wr = hp.x * p1, wi = hp.y * p1;
+          const cplx hv = radial(n, hp);
+          const double wr = hv.x * p1, wi = hv.y * p1;
           sr += wr * cp.x - wi * cp.y; si += wr * cp.y + wi * cp.x;
           if (m > 0) { const cplx cn = sC[n * n + n - m]; qr += wr * cn.x - wi * cn.y; qi += wr * cn.y + wi * cn.x; }
           const int q = n + 1;
@@ -372,32 +468,38 @@ int launch_uscat(const biem_plan* p, int nb, int B, int P, const double* d_k, co
                      geom_batched, (const cplx*)d_density, c, scratch);
   BIEM_LAUNCHCHK();
   if (scratch) BIEM_HIPCHK(hipFreeAsync(scratch, st));
-  // (the far field does not depend on the kind; the near field of kind inner needs j_n: the generic kernel)
+  // the far field does not depend on the kind; the near field of kind inner reads j_n from a per-lane LDS row (INNER)
   const bool far = (flags & BIEM_USCAT_FAR_FIELD) != 0;
-  const bool fast_ok = far || !(flags & BIEM_USCAT_KIND_INNER);
-  if (fast_ok && !getenv("BIEM_USCAT_GENERIC") && nb <= 65535 &&
-      ((p->tree == TREE_BA && p->n_end <= kFastNendMax3) || (p->tree == TREE_A && (big || p->n_end <= kFastNendMax2)) ||
-       (p->tree == TREE_BBA && p->n_end <= kFastNendMax4))) {
-    const int ne = p->n_end;
-    if (p->tree == TREE_BA) {
-      const size_t shm = (size_t)(2 * ne * ne + ((ne + 1) & ~1)) * sizeof(double) + (size_t)ne * ne * sizeof(cplx);
-#define BIEM_USCAT_FAST(TREE, FARF)                                                                                             \
+  const bool inner = !far && (flags & BIEM_USCAT_KIND_INNER);
+  const int ne = p->n_end, ms = 2 * ne - 1;
+  const bool fast_tree = (p->tree == TREE_BA && ne <= kFastNendMax3) || (p->tree == TREE_A && (big || ne <= kFastNendMax2)) ||
+                         (p->tree == TREE_BBA && ne <= kFastNendMax4) || (p->tree == TREE_CAA && ne <= kFastNendMaxCaa);
+  if (fast_tree && !getenv("BIEM_USCAT_GENERIC") && nb <= 65535) {
+    const int T = inner ? 64 : 256;
+    size_t tab = 0, nC = 0;               // doubles of tables, complex of coefficients (the layout at the head of k_uscat_fast)
+    if (p->tree == TREE_BA) { tab = (size_t)2 * ne * ne + ((ne + 1) & ~1); nC = (size_t)ne * ne; }
+    else if (p->tree == TREE_BBA) { tab = (size_t)4 * ne * ne + 2 * ((ne + 1) & ~1); nC = (size_t)ne * ne * ms; }
+    else if (p->tree == TREE_CAA) { tab = (size_t)4 * ne * ne * ((ne + 1) / 2); nC = (size_t)ne * ms * ms; }
+    else nC = (size_t)ms;
+    const size_t shm = tab * sizeof(double) + (nC + (inner ? (size_t)T * ((ne + 2) | 1) : 0)) * sizeof(cplx);
+    if (shm <= 160 * 1024) {
+#define BIEM_USCAT_FAST(TREE, FARF, INNERF)                                                                                      \
   {                                                                                                                              \
-    BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_uscat_fast<TREE, FARF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
-    hipLaunchKernelGGL((k_uscat_fast<TREE, FARF>), dim3((P + 255) / 256, nb), dim3(256), shm, st, p->d, p->H, ne, p->d_labels, nb, \
+    BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_uscat_fast<TREE, FARF, INNERF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
+    hipLaunchKernelGGL((k_uscat_fast<TREE, FARF, INNERF>), dim3((P + T - 1) / T, nb), dim3(T), shm, st, p->d, p->H, ne, p->d_labels, nb, \
                        B, P, (const cplx*)d_k, d_centers, d_radii, geom_batched, (const cplx*)c, d_points, flags, (cplx*)d_out); \
   }
-      if (far) BIEM_USCAT_FAST(TREE_BA, true) else BIEM_USCAT_FAST(TREE_BA, false)
-    } else if (p->tree == TREE_BBA) {
-      const size_t shm = (size_t)(4 * ne * ne + 2 * ((ne + 1) & ~1)) * sizeof(double) + (size_t)ne * ne * (2 * ne - 1) * sizeof(cplx);
-      if (far) BIEM_USCAT_FAST(TREE_BBA, true) else BIEM_USCAT_FAST(TREE_BBA, false)
-    } else {
-      const size_t shm = (size_t)(2 * ne - 1) * sizeof(cplx);
-      if (far) BIEM_USCAT_FAST(TREE_A, true) else BIEM_USCAT_FAST(TREE_A, false)
+#define BIEM_USCAT_FAST_TREE(TREE)                                                                                               \
+  { if (far) BIEM_USCAT_FAST(TREE, true, false) else if (inner) BIEM_USCAT_FAST(TREE, false, true) else BIEM_USCAT_FAST(TREE, false, false) }
+      if (p->tree == TREE_BA) BIEM_USCAT_FAST_TREE(TREE_BA)
+      else if (p->tree == TREE_BBA) BIEM_USCAT_FAST_TREE(TREE_BBA)
+      else if (p->tree == TREE_CAA) BIEM_USCAT_FAST_TREE(TREE_CAA)
+      else BIEM_USCAT_FAST_TREE(TREE_A)
+#undef BIEM_USCAT_FAST_TREE
 #undef BIEM_USCAT_FAST
+      BIEM_LAUNCHCHK();
+      return BIEM_OK;
     }
-    BIEM_LAUNCHCHK();
-    return BIEM_OK;
   }
   hipLaunchKernelGGL(k_uscat, dim3(P, nb), dim3(256), (size_t)B * sizeof(cplx), st, p->tree, p->d, p->H, p->n_end, p->d_labels,
                      p->d_deg, nb, B, P, (const cplx*)d_k, d_centers, d_radii, geom_batched, (const cplx*)c, d_points, flags, (cplx*)d_out);

@@ -69,6 +69,7 @@ BIEM_HD void bessel_jy_int(int nmax, double x, double* J, double* Y) {
   double inv = 1.0 / norm;
   for (int q = 0; q <= nmax; ++q) J[q] *= inv;
   s0 *= inv; s1 *= inv;
+  if (Y == nullptr) return;                     // regular functions only
   double j0 = jc * inv, j1 = jp1 * inv;
   double lg = log(0.5 * x) + kEulerGamma;
   double y0 = (2.0 / kPi) * (lg * j0 - 2.0 * s0);
@@ -105,6 +106,7 @@ BIEM_HD void bessel_jy_sph(int nmax, double x, double* J, double* Y) {
   double j0 = s * ix, j1 = (s * ix - c) * ix;
   double scale = (fabs(j0) >= fabs(j1)) ? j0 / jc : j1 / jp1;
   for (int q = 0; q <= nmax; ++q) J[q] *= scale;
+  if (Y == nullptr) return;                     // regular functions only
   double y0 = -c * ix, y1 = (-c * ix - s) * ix;
   Y[0] = y0;
   if (nmax >= 1) Y[1] = y1;
@@ -121,11 +123,11 @@ BIEM_HD void radial_d(int d, int nmax, double x, double* J, double* Y) {
     bessel_jy_sph(nmax, x, J, Y);
   } else if (d == 2) {
     bessel_jy_int(nmax, x, J, Y);
-    for (int n = 0; n <= nmax; ++n) { J[n] *= kSqrtHalfPi; Y[n] *= kSqrtHalfPi; }
+    for (int n = 0; n <= nmax; ++n) { J[n] *= kSqrtHalfPi; if (Y) Y[n] *= kSqrtHalfPi; }
   } else {  // d == 4: sqrt(pi/2) Z_{n+1}(x) / x
     bessel_jy_int(nmax + 1, x, J, Y);
     double f = kSqrtHalfPi / x;
-    for (int n = 0; n <= nmax; ++n) { J[n] = J[n + 1] * f; Y[n] = Y[n + 1] * f; }
+    for (int n = 0; n <= nmax; ++n) { J[n] = J[n + 1] * f; if (Y) Y[n] = Y[n + 1] * f; }
   }
 }
 
@@ -197,6 +199,7 @@ BIEM_HD void bessel_jh_sph_c(int nmax, zc z, zc* J, zc* H) {
   zc j0 = zmul(sn, iz), j1 = zmul(zsub(zmul(sn, iz), cs), iz);
   zc scale = (zabs1(j0) >= zabs1(j1)) ? zdiv(j0, jc) : zdiv(j1, jp1);
   for (int q = 0; q <= nmax; ++q) J[q] = zmul(J[q], scale);
+  if (H == nullptr) return;                     // regular functions only
   // h_0 = -i e^{iz} / z,  h_1 = -(z + i) e^{iz} / z^2
   zc e = zexp(zmk(-z.y, z.x));
   zc h0 = zmul(zmk(e.y, -e.x), iz);                         // -i e
@@ -291,6 +294,7 @@ BIEM_HD void bessel_jh_int_c(int nmax, zc z, zc* J, zc* H) {
   zc target = up ? zexp(zmk(z.y, -z.x)) : zexp(zmk(-z.y, z.x));   // e^{-iz} or e^{+iz}
   zc scale = zdiv(target, norm);
   for (int q = 0; q <= nmax; ++q) J[q] = zmul(J[q], scale);
+  if (H == nullptr) return;                     // regular functions only
   // H_0, H_1 at zz = z (Im z >= 0) or conj z
   zc zz = up ? z : zmk(z.x, -z.y);
   zc w = zmk(zz.y, -zz.x);                                 // -i zz
@@ -312,24 +316,25 @@ BIEM_HD void bessel_jh_int_c(int nmax, zc z, zc* J, zc* H) {
 }
 
 // d-dimensional regular and outgoing radial functions at a complex argument; real arguments (Im z == 0) take the real
-// routines above (bit-identical to the real-k path).  J, H: nmax + 1 entries (d = 4: nmax + 2 slots each).
+// routines above (bit-identical to the real-k path).  J, H: nmax + 1 entries (d = 4: nmax + 2 slots each).  H == nullptr: the
+// regular functions only (the outgoing ones are not computed).
 BIEM_HD void radial_jh(int d, int nmax, zc z, zc* J, zc* H) {
   if (z.y == 0.0) {
     double* Jd = (double*)J;
     double* Yd = (double*)H;
     radial_d(d, nmax, z.x, Jd, Yd);        // reals in the first nmax + 1 (+1) doubles of each buffer
-    for (int n = nmax; n >= 0; --n) { double j = Jd[n], y = Yd[n]; J[n] = zmk(j, 0.0); H[n] = zmk(j, y); }
+    for (int n = nmax; n >= 0; --n) { double j = Jd[n]; if (H) H[n] = zmk(j, Yd[n]); J[n] = zmk(j, 0.0); }
     return;
   }
   if (d == 3) {
     bessel_jh_sph_c(nmax, z, J, H);
   } else if (d == 2) {
     bessel_jh_int_c(nmax, z, J, H);
-    for (int n = 0; n <= nmax; ++n) { J[n] = zscl(J[n], kSqrtHalfPi); H[n] = zscl(H[n], kSqrtHalfPi); }
+    for (int n = 0; n <= nmax; ++n) { J[n] = zscl(J[n], kSqrtHalfPi); if (H) H[n] = zscl(H[n], kSqrtHalfPi); }
   } else {
     bessel_jh_int_c(nmax + 1, z, J, H);
     zc f = zscl(zinv(z), kSqrtHalfPi);
-    for (int n = 0; n <= nmax; ++n) { J[n] = zmul(J[n + 1], f); H[n] = zmul(H[n + 1], f); }
+    for (int n = 0; n <= nmax; ++n) { J[n] = zmul(J[n + 1], f); if (H) H[n] = zmul(H[n + 1], f); }
   }
 }
 

@@ -553,10 +553,11 @@ def test_small_systems_one_launch_path(amd, bt, d, n_end, B, monkeypatch):
         assert np.max(np.abs(u_small[:, i] - ref)) < 1e-10 * np.max(np.abs(ref)), i
 
 
-@pytest.mark.parametrize("bt,d,n_end,B", [("ba", 3, 7, 3), ("a", 2, 11, 4), ("bpa", 3, 5, 2), ("ba", 3, 20, 2), ("bba", 4, 6, 3), ("bpbpa", 4, 5, 2), ("bba", 4, 10, 2)])
+@pytest.mark.parametrize("bt,d,n_end,B", [("ba", 3, 7, 3), ("a", 2, 11, 4), ("bpa", 3, 5, 2), ("ba", 3, 20, 2), ("bba", 4, 6, 3), ("bpbpa", 4, 5, 2), ("bba", 4, 10, 2),
+                                          ("caa", 4, 6, 3), ("caa", 4, 12, 2), ("caa", 4, 1, 2)])
 def test_uscat_point_per_lane_matches_generic(amd, bt, d, n_end, B, monkeypatch):
-    """Near-field evaluation for kind = "outer" and the far field on trees a / ba / bpa / bba / bpbpa run one point per lane with recurrences for
-    h_n, Pbar_n^m and e^{i m phi} (k_uscat_fast); BIEM_USCAT_GENERIC=1 forces the harmonic-by-harmonic kernel.  Same results (1e-12), incl. per_ball,
+    """Near-field evaluation for kind = "outer" and the far field on trees a / ba / bpa / bba / bpbpa / caa run one point per lane with recurrences for
+    h_n, the polar factors and e^{i m phi} (k_uscat_fast); BIEM_USCAT_GENERIC=1 forces the harmonic-by-harmonic kernel.  Same results (1e-12), incl. per_ball,
     points given per system, complex k, NaN inside the balls and a point count that is not a multiple of the workgroup size."""
     c = amd.create_from_branching_types(bt)
     rng = np.random.default_rng(n_end + B)
@@ -589,6 +590,41 @@ def test_uscat_point_per_lane_matches_generic(amd, bt, d, n_end, B, monkeypatch)
             assert not np.isnan(f.real).any()                              # the far field is defined everywhere
         ok = ~np.isnan(g.real)
         assert np.max(np.abs(f[ok] - g[ok])) < 1e-12 * np.max(np.abs(g[ok])), i
+
+
+@pytest.mark.parametrize("bt,d,n_end,kval", [("a", 2, 9, 1.7), ("a", 2, 40, 30.0), ("ba", 3, 7, 2.0 + 0.3j), ("ba", 3, 20, 25.0), ("ba", 3, 48, 11.0),
+                                             ("bpa", 3, 6, 3.0), ("bba", 4, 6, 2.2), ("bba", 4, 14, 9.0 - 0.4j), ("caa", 4, 7, 2.0), ("caa", 4, 12, 14.0)])
+def test_uscat_inner_point_per_lane_matches_generic(amd, bt, d, n_end, kval, monkeypatch):
+    """kind = "inner": the per-lane kernel keeps j_0 .. j_{n_end-1}(k r) of its point in an LDS row (backward recurrence, once per
+    ball) and walks the harmonics as for the exterior.  Same results as the harmonic-by-harmonic kernel (1e-12 of the largest
+    value), with k r on both sides of n_end, a complex wavenumber, the centre of the ball, points outside (NaN), per_ball and a
+    point count that is no multiple of the workgroup."""
+    c = amd.create_from_branching_types(bt)
+    rng = np.random.default_rng(n_end)
+    cen, rad = 0.3 * rng.normal(size=(1, d)), np.array([1.3])
+    ks = np.array([kval, 0.6 * kval])
+    dirs = np.zeros((d, len(ks))); dirs[0] = 1.0
+    uin, ugr = amd.plane_wave(k=_dev(ks, torch.complex128), direction=_dev(dirs))
+    calc = amd.biem(c, centers=_dev(cen)[None], radii=_dev(rad)[None], k=_dev(ks, torch.complex128), n_end=n_end, alpha=1.0, beta=0.2,
+                    uin=uin, uin_grad=ugr, kind="inner")
+    x = rng.normal(size=(150, d))
+    x *= (rad[0] * rng.uniform(0.01, 0.999, size=150) / np.linalg.norm(x, axis=1))[:, None]
+    x += cen[0]
+    x[0] = cen[0]                                                     # the centre
+    x[1] = cen[0] + 1.2 * rad[0] * np.eye(d)[0]                       # outside -> NaN
+    x[2] = cen[0] + 0.5 * rad[0] * np.eye(d)[d - 1]                   # on an axis (degenerate azimuth)
+
+    def run():
+        return calc.uscat(_dev(x.T)).cpu().numpy(), calc.uscat(_dev(x.T), per_ball=True).cpu().numpy()
+
+    fast = run()
+    monkeypatch.setenv("BIEM_USCAT_GENERIC", "1")
+    gen = run()
+    for f, g in zip(fast, gen):
+        assert f.shape == g.shape and np.array_equal(np.isnan(f.real), np.isnan(g.real))
+        assert np.isnan(f[1]).all() and not np.isnan(f[0]).any() and not np.isnan(f[2:]).any()
+        ok = ~np.isnan(g.real)
+        assert np.max(np.abs(f[ok] - g[ok])) < 1e-12 * np.max(np.abs(g[ok]))
 
 
 def test_pair_classes_at_the_top_of_the_2d_range(amd, monkeypatch):
@@ -952,7 +988,7 @@ def test_factor_now_solve_later(lib, N, nb, nrhs, sym):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tree", ["a", "ba", "bba"])
+@pytest.mark.parametrize("tree", ["a", "ba", "bba", "caa"])
 def test_kind_inner_interior_expansion(amd, tree):
     """kind="inner" (reference :971-976 keeps the points with r <= rho): there the layer potentials expand in the REGULAR
     functions.  No reference fixture covers it (parity unpinned), so besides the oracle the test checks what defines the
