@@ -1011,7 +1011,10 @@ static int launch_gemm_stream(hipStream_t st, int nb, cplx* A, long long lda, lo
   // XCD's L2).  A small launch - one system, or the last groups of a factorisation - would leave most workgroups without a
   // tile that way (63 tiles: all in block 0, i.e. on the 8 workgroups of one label, 8 tiles each in sequence: 204 us for a
   // K = 192 tile row of one N = 4064 system): blocks of 8 tiles then.
-  tg.blk_sh = tg.ntiles < 2048 ? 3 : 6;
+  // Up to 512 tiles every tile has its own workgroup: tile = blockIdx (a block of ONE tile per label and round) - with blocks of 8 a
+  // 33-tile launch (the strip of one system half-way through its factorisation) ran on the workgroups of 5 labels, several of them
+  // taking two tiles in sequence while three quarters of the grid had none: 29.5 us per K = 64 strip launch instead of 13.
+  tg.blk_sh = tg.ntiles <= 512 ? 0 : tg.ntiles < 2048 ? 3 : 6;
   tg.per_sys_magic = ((1ULL << 40) + (unsigned long long)tg.per_sys - 1) / (unsigned long long)tg.per_sys;
   if (tg.ntiles >= (1 << 25)) { set_error("biem_lu: more than 2^25 tiles in one update launch"); return BIEM_ERR_ARG; }   // unreachable: 2^25 tiles are 2 TB of matrix
   tg.row_begin = row_begin; tg.row_end = row_end; tg.col_begin = col_begin; tg.col_end = col_end; tg.brow = brow;
@@ -2158,6 +2161,30 @@ extern "C" int biem_debug_gemm(int nb, int n, int kd, int reps, unsigned long lo
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms = 0; hipEventElapsedTime(&ms, e0, e1); *ms_out = ms / reps;
   hipMemcpyFromSymbol(trace_out, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * 16 * 64 * 8);
+  hipFree(A); hipFree(P);
+  return 0;
+}
+// one small update launch, as a single system sees it: C[r0 : r0 + rows, 0 : n] -= P^T M[brow ..], `reps` launches back to back; cold = 1:
+// every launch takes another row strip (the matrix is far larger than the caches), cold = 0: the same one
+extern "C" int biem_debug_gemm_strip(int n, int kd, int rows, int reps, int cold, float* us_out, int extra_cols, int col0) {
+  const long long lda = n + 8, ldp = n + 256;
+  cplx *A = nullptr, *P = nullptr;
+  const size_t na = (size_t)(n + 256) * lda, np = (size_t)256 * ldp;
+  if (hipMalloc((void**)&A, na * sizeof(cplx)) != hipSuccess) return 1;
+  if (hipMalloc((void**)&P, np * sizeof(cplx)) != hipSuccess) return 1;
+  hipLaunchKernelGGL(k_trace_fill, dim3(2048), dim3(256), 0, 0, (double*)A, na * 2);
+  hipLaunchKernelGGL(k_trace_fill, dim3(2048), dim3(256), 0, 0, (double*)P, np * 2);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int nstrips = (n - rows) / 64;
+  for (int r = 0; r < 3; ++r) launch_gemm_stream(0, 1, A, lda, 0, P, ldp, 0, 256, 256 + rows, col0, n + extra_cols, 0, kd);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  for (int r = 0; r < reps; ++r) {
+    const int r0 = 256 + (cold ? 64 * ((r * 7) % nstrips) : 0);
+    launch_gemm_stream(0, 1, A, lda, 0, P, ldp, 0, r0, r0 + rows, col0, n + extra_cols, cold ? r0 : 0, kd);
+  }
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1); *us_out = ms * 1e3f / reps;
   hipFree(A); hipFree(P);
   return 0;
 }
