@@ -696,7 +696,11 @@ def biem(
                           _ptr(fl.alpha), _ptr(fl.beta), fl.ab_batched, _ptr(g), _ptr(density_t), _ptr(info), chunk,
                           _ptr(work), wbytes, sp), "biem_solve")
             if solver == "ldlt":
-                redo = torch.nonzero(info < 0).flatten()
+                # (the codes come to the host in ONE copy and the rejected systems are picked there: torch.nonzero on the device is five
+                # launches and a synchronisation of its own, which one system per call pays in full)
+                info_h = info.cpu()
+                redo_h = torch.nonzero(info_h < 0).flatten()
+                redo = redo_h.to(dev) if redo_h.numel() > 0 else redo_h
                 if redo.numel() > 0:
                     nr = int(redo.numel())
                     pick = lambda t, batched: t[redo].contiguous() if batched else t
@@ -715,7 +719,7 @@ def biem(
             # -(n_pad + 1) for the growth check
             _last_solve_stats.pop("rejected_info", None)
             if solver == "ldlt" and redo.numel() > 0:
-                _last_solve_stats["rejected_info"] = info[redo].tolist()[:64]
+                _last_solve_stats["rejected_info"] = info_h[redo_h].tolist()[:64]
             del work
 
     def make_matrix():

@@ -1431,6 +1431,48 @@ __global__ void __launch_bounds__(256) k_rhs_project(int H, int Q, int rows, int
   }
 }
 
+// Few rows (one system per call: B nrhs rows): the form above leaves the whole sum over q to (H / 256) x (rows / RT) workgroups - 4 at cfg 3,
+// 435 us.  Here a workgroup takes 16 harmonics and splits the quadrature points over its 16 lane groups (partial sums reduced through
+// LDS in a fixed order: deterministic), so H / 16 workgroups per row block share the stream of W.
+template <int RT>
+__global__ void __launch_bounds__(256) k_rhs_project_few(int H, int Q, int rows, int B, int nrhs, const cplx* __restrict__ g,
+                                                          const cplx* __restrict__ W, cplx* __restrict__ f, long long sys_stride,
+                                                          long long elem_stride, long long rhs_stride, const int* __restrict__ hpos) {
+  extern __shared__ cplx sg[];   // [RT][QC]; afterwards the partial sums [16 slices][RT][16]
+  constexpr int QC = 256;
+  const int row0 = blockIdx.y * RT;
+  const int hl = threadIdx.x & 15, qs = threadIdx.x >> 4;
+  const int h = blockIdx.x * 16 + hl, hc = h < H ? h : H - 1;
+  cplx acc[RT];
+  for (int r = 0; r < RT; ++r) acc[r] = make_double2(0.0, 0.0);
+  for (int q0 = 0; q0 < Q; q0 += QC) {
+    const int qn = min(QC, Q - q0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < RT * QC; i += 256) {
+      const int r = i / QC, q = i % QC;
+      sg[i] = (row0 + r < rows && q < qn) ? g[(size_t)(row0 + r) * Q + q0 + q] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    for (int q = qs; q < qn; q += 16) {
+      const cplx w = W[(size_t)(q0 + q) * H + hc];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) acc[r] = cfma(sg[r * QC + q], w, acc[r]);
+    }
+  }
+  __syncthreads();
+  for (int r = 0; r < RT; ++r) sg[(qs * RT + r) * 16 + hl] = acc[r];
+  __syncthreads();
+  if (threadIdx.x < RT * 16) {
+    const int r = threadIdx.x >> 4, row = row0 + r;
+    cplx t = make_double2(0.0, 0.0);
+    for (int z = 0; z < 16; ++z) { const cplx v = sg[(z * RT + r) * 16 + hl]; t.x += v.x; t.y += v.y; }
+    if (row < rows && h < H) {
+      long long b = row % B, sr = row / B, rr = sr % nrhs, sy = sr / nrhs;     // row = (s*nrhs + rr)*B + b
+      f[(size_t)sy * sys_stride + ((size_t)b * H + (hpos ? hpos[h] : h)) * elem_stride + (size_t)rr * rhs_stride] = t;
+    }
+  }
+}
+
 int launch_rhs_project(const biem_plan* p, int nb, int B, int nrhs, const double* d_g, double* d_f, long long sys_stride,
                        long long elem_stride, long long rhs_stride, hipStream_t st, bool slot_order) {
   if (nrhs < 1) { set_error("biem_rhs_project: nrhs < 1"); return BIEM_ERR_ARG; }
@@ -1439,6 +1481,13 @@ int launch_rhs_project(const biem_plan* p, int nb, int B, int nrhs, const double
   constexpr int RT = 8;
   size_t shm = (size_t)RT * 256 * sizeof(cplx);
   ProfScope ps(PK_RHS, st, 8.0 * (double)rows * p->Q * p->H);
+  if ((long long)((p->H + 255) / 256) * ((rows + RT - 1) / RT) < 128) {
+    hipLaunchKernelGGL(k_rhs_project_few<RT>, dim3((p->H + 15) / 16, (rows + RT - 1) / RT), dim3(256), shm, st, p->H, p->Q, rows, B,
+                       nrhs, (const cplx*)d_g, (const cplx*)p->d_W, (cplx*)d_f, sys_stride, elem_stride, rhs_stride,
+                       slot_order ? p->d_hpos : nullptr);
+    BIEM_LAUNCHCHK();
+    return BIEM_OK;
+  }
   hipLaunchKernelGGL(k_rhs_project<RT>, dim3((p->H + 255) / 256, (rows + RT - 1) / RT), dim3(256), shm, st, p->H, p->Q, rows, B,
                      nrhs, (const cplx*)d_g, (const cplx*)p->d_W, (cplx*)d_f, sys_stride, elem_stride, rhs_stride,
                      slot_order ? p->d_hpos : nullptr);

@@ -15,6 +15,7 @@
 #include "common.hpp"
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 namespace biem {
 
@@ -1082,6 +1083,12 @@ __global__ void __launch_bounds__(64) k_swap_p(cplx* __restrict__ Pw, long long 
 // ---------------------------------------------------------------------------------------------
 // The right-hand sides are addressed as F[s * f_stride + row * ldf + q]: the augmented columns of the matrix itself
 // (F = A + n_pad, ldf = lda, f_stride = sys_stride) in the fused solve, a separate array in biem_lu_solve.
+// value of lane i (WAVE-UNIFORM i) in every lane: two v_readlane_b32 through the scalar file instead of the LDS crossbar round trip
+// of ds_bpermute (__shfl) - these broadcasts sit on the dependent chain of the elimination / substitution steps
+__device__ inline double lane_bcast(double v, int i) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), i), hi = __builtin_amdgcn_readlane(__double2hiint(v), i);
+  return __hiloint2double(hi, lo);
+}
 // diagonal block: x = U[jr:jr+BS, jr:jr+BS]^{-1} y, one 64-thread workgroup per (system, rhs)
 __global__ void __launch_bounds__(64) k_back_diag(const cplx* __restrict__ A, long long lda, long long sys_stride, cplx* __restrict__ F,
                                                    long long ldf, long long f_stride, int jr) {
@@ -1097,7 +1104,7 @@ __global__ void __launch_bounds__(64) k_back_diag(const cplx* __restrict__ A, lo
   const cplx inv = crecip(sU[r][r]);           // every lane its own diagonal entry, once
   for (int c = BS - 1; c >= 0; --c) {
     const cplx t = cmul(y, inv);               // lane c holds x_c
-    const cplx xc = make_double2(__shfl(t.x, c, 64), __shfl(t.y, c, 64));
+    const cplx xc = make_double2(lane_bcast(t.x, c), lane_bcast(t.y, c));
     if (r == c) y = xc;
     if (r < c) y = cfnma(sU[r][c], xc, y);
   }
@@ -1186,6 +1193,75 @@ __global__ void __launch_bounds__(256) k_back_update(const cplx* __restrict__ A,
   }
 }
 
+// One block step of the back substitution with the STORED inverses of the diagonal blocks (few systems per call: the chain of
+// 2 n / 64 dependent launches is what one system per call waits for).  The factorisation keeps W_b = I - U_bb^{-T} of every panel
+// (stored [k][i] = delta_ki - (U_bb^{-1})[k][i]), so  x_b = U_bb^{-1} y_b = y_b - sum_{i >= k} W_b[k][i] y_i  is a 64 x 64 product that
+// every workgroup of the update forms for itself - no 64-step triangular solve (k_back_diag: 12 us) and one launch per block instead
+// of two.  y_b must not be overwritten while other workgroups read it: the solution goes to X[(s nrhs + q) n_pad + row] and is copied
+// back at the end (k_rhs_compact).  The update of the rows above (and the checks of the entries it reads) is k_back_update's.
+__global__ void __launch_bounds__(256) k_back_step(const cplx* __restrict__ A, long long lda, long long sys_stride, cplx* __restrict__ F,
+                                                    long long ldf, long long f_stride, const cplx* __restrict__ Wall, long long w_stride,
+                                                    cplx* __restrict__ X, int n_pad, int nrhs, int jr, int* __restrict__ info,
+                                                    unsigned long long* __restrict__ growth, double inv_rel2) {
+  __shared__ cplx sx[BS], syb[BS];
+  const int s = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const cplx* As = A + (size_t)s * sys_stride;
+  cplx* Fs = F + (size_t)s * f_stride;
+  const cplx* Wb = Wall + (size_t)s * w_stride + (size_t)(jr / NB) * NB * NB;
+  cplx u[BACK_ROWS / 4];
+  const int i0 = blockIdx.x * BACK_ROWS + wave * (BACK_ROWS / 4);
+#pragma unroll
+  for (int k = 0; k < BACK_ROWS / 4; ++k) u[k] = (i0 + k < jr) ? As[(size_t)(i0 + k) * lda + jr + lane] : make_double2(0.0, 0.0);
+  // this wave's 16 rows of W_b (lanes along i): loaded once, used by every right-hand side
+  cplx wr[16];
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) { const int k = wave * 16 + kk; wr[kk] = lane >= k ? Wb[k * NB + lane] : make_double2(0.0, 0.0); }
+  {
+    double um2 = 0.0;
+    bool badm = false;
+#pragma unroll
+    for (int k = 0; k < BACK_ROWS / 4; ++k) {
+      if (i0 + k >= jr) break;
+      const cplx d = As[(size_t)(i0 + k) * lda + i0 + k];
+      const double m2 = u[k].x * u[k].x + u[k].y * u[k].y, d2 = d.x * d.x + d.y * d.y;
+      if (!(m2 <= inv_rel2 * d2)) badm = true;
+      um2 = nan_max(um2, m2 * d2);
+    }
+    block_max_publish(sqrt(um2), growth + 2 * (size_t)s + 1);
+    if (badm && info[s] == 0) info[s] = -((i0 / NB) * NB + 1);
+  }
+  for (int q = 0; q < nrhs; ++q) {
+    __syncthreads();
+    if (threadIdx.x < BS) syb[threadIdx.x] = Fs[(size_t)(jr + threadIdx.x) * ldf + q];
+    __syncthreads();
+    const cplx yl = syb[lane];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const cplx v = cmul(wr[kk], yl);
+      double vr = v.x, vi = v.y;
+      for (int o = 32; o > 0; o >>= 1) { vr += __shfl_down(vr, o, 64); vi += __shfl_down(vi, o, 64); }
+      if (lane == 0) { const int k = wave * 16 + kk; sx[k] = make_double2(syb[k].x - vr, syb[k].y - vi); }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < BS) X[((size_t)s * nrhs + q) * n_pad + jr + threadIdx.x] = sx[threadIdx.x];
+    const cplx x = sx[lane];
+#pragma unroll
+    for (int k = 0; k < BACK_ROWS / 4; ++k) {
+      const int i = i0 + k;
+      if (i >= jr) break;
+      const cplx v = cmul(u[k], x);
+      double vr = v.x, vi = v.y;
+      for (int o = 32; o > 0; o >>= 1) { vr += __shfl_down(vr, o, 64); vi += __shfl_down(vi, o, 64); }
+      if (lane == 0) {
+        cplx* y = Fs + (size_t)i * ldf + q;
+        cplx t = *y;
+        t.x -= vr; t.y -= vi;
+        *y = t;
+      }
+    }
+  }
+}
+
 __global__ void k_zero_int(int* p, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0;
@@ -1217,27 +1293,40 @@ __global__ void __launch_bounds__(64) k_rhs_panel(cplx* __restrict__ A, long lon
   F[(size_t)(j + r) * lda] = y;
 }
 
-// rows below a group: f[i] -= L[i, 0:kd] y[jg : jg+kd]; one thread per row, the kd values of y in LDS
+// rows below a group: f[i] -= L[i, 0:kd] y[jg : jg+kd]; a workgroup takes 64 rows, its four waves a quarter of the kd terms each
+// (one thread per row over all kd terms left one system's update on n / 256 workgroups with 256 dependent loads per thread:
+// 22 us per launch at N = 4064); the kd values of y in LDS
+constexpr int RHS_UPD_ROWS = 64;
 __global__ void __launch_bounds__(256) k_rhs_update(cplx* __restrict__ A, long long lda, long long sys_stride, const cplx* __restrict__ Pw,
                                                      long long ldp, long long p_stride, int n_pad, int row_begin, int jg, int kd) {
   __shared__ cplx sy[4 * NB];
+  __shared__ cplx part[3][64];
   const int s = blockIdx.y, q = blockIdx.z;
   cplx* F = A + (size_t)s * sys_stride + n_pad + q;
   for (int k = threadIdx.x; k < kd; k += 256) sy[k] = F[(size_t)(jg + k) * lda];
   __syncthreads();
-  const int i = row_begin + blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_pad) return;
-  const cplx* Pr = Pw + (size_t)s * p_stride + i;
+  const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6;
+  const int i = row_begin + blockIdx.x * RHS_UPD_ROWS + lane, ic = i < n_pad ? i : n_pad - 1;
+  const cplx* Pr = Pw + (size_t)s * p_stride + ic;
+  const int k0 = (kd >> 2) * kq, k1 = kq == 3 ? kd : k0 + (kd >> 2);       // kd is a multiple of 4 here (64 .. 256)
   cplx a0 = make_double2(0.0, 0.0), a1 = a0, a2 = a0, a3 = a0;
-  for (int k = 0; k < kd; k += 4) {
+  int k = k0;
+  for (; k + 3 < k1; k += 4) {
     a0 = cfma(Pr[(size_t)k * ldp], sy[k], a0);
     a1 = cfma(Pr[(size_t)(k + 1) * ldp], sy[k + 1], a1);
     a2 = cfma(Pr[(size_t)(k + 2) * ldp], sy[k + 2], a2);
     a3 = cfma(Pr[(size_t)(k + 3) * ldp], sy[k + 3], a3);
   }
-  cplx f = F[(size_t)i * lda];
-  f.x -= (a0.x + a1.x) + (a2.x + a3.x); f.y -= (a0.y + a1.y) + (a2.y + a3.y);
-  F[(size_t)i * lda] = f;
+  for (; k < k1; ++k) a0 = cfma(Pr[(size_t)k * ldp], sy[k], a0);
+  const cplx sum = make_double2((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y));
+  if (kq > 0) part[kq - 1][lane] = sum;
+  __syncthreads();
+  if (kq == 0 && i < n_pad) {
+    cplx f = F[(size_t)i * lda];
+    f.x -= (sum.x + part[0][lane].x) + (part[1][lane].x + part[2][lane].x);
+    f.y -= (sum.y + part[0][lane].y) + (part[1][lane].y + part[2][lane].y);
+    F[(size_t)i * lda] = f;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1505,7 +1594,7 @@ int launch_lu_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long l
                          nullptr, 0, 0, 0, tri_map);
       if (rhs_gemv) {
         ProfScope ps(PK_OTHER, st, 0.0);
-        hipLaunchKernelGGL(k_rhs_update, dim3((n_pad - (J + 4 * NB) + 255) / 256, nb, nrhs), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp,
+        hipLaunchKernelGGL(k_rhs_update, dim3((n_pad - (J + 4 * NB) + RHS_UPD_ROWS - 1) / RHS_UPD_ROWS, nb, nrhs), dim3(256), 0, st, A, lda, sys_stride, Pw, ldp,
                            p_stride, n_pad, J + 4 * NB, J, 4 * NB);
       } else if (nrhs > 0) {
         gemm(st, nb, A, lda, sys_stride, Pw, ldp, p_stride, J + 4 * NB, n_pad, n_pad, n_cols, J, 4 * NB, PK_OTHER);
@@ -1684,7 +1773,7 @@ __global__ void __launch_bounds__(1024) k_back_row(const cplx* __restrict__ A, l
       cplx y = sy[lane][q];
       for (int c = NB - 1; c >= 0; --c) {
         if (lane == c) y = cmul(y, crecip(sU[c][c]));
-        const double xr = __shfl(y.x, c, 64), xi = __shfl(y.y, c, 64);
+        const double xr = lane_bcast(y.x, c), xi = lane_bcast(y.y, c);
         if (lane < c) y = cfnma(sU[lane][c], make_double2(xr, xi), y);
       }
       Ys[(size_t)(q0 + q) * n_pad + rb + lane] = y;
@@ -1760,8 +1849,8 @@ __global__ void __launch_bounds__(SMALL_THREADS, (KR <= 9 ? 4 : 2)) k_small_utu(
   // overflow would surface as inf / NaN in the growth test)
   auto publish = [&](int i, const cplx& r0, const cplx& r1) {
     cplx d;
-    if (!TWO || i < 64) { d.x = __shfl(r0.x, i & 63, 64); d.y = __shfl(r0.y, i & 63, 64); }
-    else { d.x = __shfl(r1.x, i & 63, 64); d.y = __shfl(r1.y, i & 63, 64); }
+    if (!TWO || i < 64) { d.x = lane_bcast(r0.x, i & 63); d.y = lane_bcast(r0.y, i & 63); }
+    else { d.x = lane_bcast(r1.x, i & 63); d.y = lane_bcast(r1.y, i & 63); }
     const double rr = fast_recip(d.x * d.x + d.y * d.y);
     const cplx ip = make_double2(d.x * rr, -d.y * rr);
     cplx* ri = sa + off(i);
@@ -1840,10 +1929,20 @@ __global__ void __launch_bounds__(SMALL_THREADS, (KR <= 9 ? 4 : 2)) k_small_utu(
 // (cfg 3: 56.4 -> 49.1 ms per 256-system step for strips + diagonal blocks; cfg 2: 61.9 -> 71.7 k systems/s, same box).
 // Writes U11 into the upper triangle of the block and W = I - U11^{-T} as W[k][i] (the A-operand order of the streaming zgemm).
 // ---------------------------------------------------------------------------------------------
-constexpr int DIAG_LDS_CPLX = 2 * (NB * (NB + 1) / 2) + 2 * NB + NB;          // packed U rows, packed L^-1 rows, multipliers [2][64], 1 / sqrt(d)
-constexpr int DIAG_THREADS = 1024;         // 16 waves x 4 rows: the step is bound by the instructions a wave issues for its rows
+#ifdef BIEM_DIAG_TRACE
+// diagnostic build only (tools/diag_trace.cpp): lane 0 of every wave of workgroup 0 stamps s_memtime at 4 points of each step
+__device__ unsigned long long g_diag_trace[16][66][4];
+#define BIEM_DT(step, i) { if (blockIdx.x == 0 && lane == 0) g_diag_trace[w][step][i] = __builtin_amdgcn_s_memtime(); }
+#else
+#define BIEM_DT(step, i)
+#endif
+constexpr int DIAG_LDS_CPLX = 2 * (NB * (NB + 1) / 2) + 2 * NB + NB + 2 * NB;          // packed U rows, packed L^-1 rows, multipliers [2][64], 1 / sqrt(d), combined rows [2][64]
+#ifndef BIEM_DIAG_THREADS
+#define BIEM_DIAG_THREADS 1024
+#endif
+constexpr int DIAG_THREADS = BIEM_DIAG_THREADS;         // 16 waves x 4 rows: the step is bound by the instructions a wave issues for its rows
 __global__ void __launch_bounds__(DIAG_THREADS) k_diag_utu_reg(cplx* __restrict__ A, long long lda, long long sys_stride, int j,
-                                                                 cplx* __restrict__ Wt, int* __restrict__ info, double rel,
+                                                                 cplx* __restrict__ Wt, long long w_stride, int* __restrict__ info, double rel,
                                                                  unsigned long long* __restrict__ growth) {
   extern __shared__ cplx sd[];
   __shared__ int bad;
@@ -1858,6 +1957,7 @@ __global__ void __launch_bounds__(DIAG_THREADS) k_diag_utu_reg(cplx* __restrict_
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: the row tests below become scalar branches
   cplx* Ab = A + (size_t)s * sys_stride + (size_t)j * lda + j;
   if (tid == 0) bad = 0;
+  BIEM_DT(64, 0)
   cplx a0[KR], y1[KR];
 #pragma unroll
   for (int k = 0; k < KR; ++k) {
@@ -1865,43 +1965,62 @@ __global__ void __launch_bounds__(DIAG_THREADS) k_diag_utu_reg(cplx* __restrict_
     a0[k] = lane >= i ? Ab[(size_t)i * lda + lane] : make_double2(0.0, 0.0);
     y1[k] = make_double2(lane == i ? 1.0 : 0.0, 0.0);
   }
+  // A finished row i is published three times: packed rows su (D L^T) and sy (L^-1) for the write-back, and for the elimination ONE
+  // combined vector comb[i & 1]: lane l <= i: (L^-1)_il (1 at l == i), lane l > i: a_il - the row-i operand of BOTH updates of a later
+  // row r > i (its D L^T part lives in lanes >= r, its L^-1 part needs lanes <= i, and (L^-1)_il = 0 for l > i) - plus the multipliers
+  // a_il / d_i in lrow[i & 1].  The step is LDS-bandwidth bound (tools/diag_trace.cpp: every wave reading the U row, the L^-1 row and a
+  // broadcast multiplier per owned row = 96 reads of 1 KB per step, 650 of 1760 traced cycles): one row read instead of two, and waves /
+  // rows that are finished read nothing.  (Multipliers taken from a vector through v_readlane instead of broadcast reads: slower,
+  // 39 -> 48 us.)
+  cplx* comb = isq + NB;                           // [2][64]
   auto publish = [&](int i, const cplx& r0, const cplx& r1) {
     cplx d;
     d.x = __shfl(r0.x, i, 64); d.y = __shfl(r0.y, i, 64);
     const double rr = fast_recip(d.x * d.x + d.y * d.y);
     const cplx ip = make_double2(d.x * rr, -d.y * rr);
+    comb[(i & 1) * NB + lane] = make_double2(lane > i ? r0.x : r1.x, lane > i ? r0.y : r1.y);   // (by value: a conditional on the references selects an address and puts the rows into scratch)
     if (lane >= i) { su[uoff(i) + lane] = r0; lrow[(i & 1) * NB + lane] = cmul(r0, ip); }
     if (lane <= i) sy[yoff(i) + lane] = r1;
   };
   if (w == 0) publish(0, a0[0], y1[0]);
   double um = 0.0;
+  BIEM_DT(64, 1)
   for (int c = 0; c < NB; ++c) {
+    BIEM_DT(c, 0)
     __syncthreads();                            // row c has been published
-    const cplx* rc = su + uoff(c);
-    const cplx* lr = lrow + (c & 1) * NB;
-    const cplx u0 = rc[lane >= c ? lane : c];
-    cplx u1 = sy[yoff(c) + (lane <= c ? lane : c)];
-    if (lane > c) u1 = make_double2(0.0, 0.0);
-    if (w == ((c + 1 + NW / 2) & (NW - 1))) {   // acceptance tests on row c, once, by a wave that does not publish the next row
-      const cplx piv = rc[c];
+    BIEM_DT(c, 1)
+    const bool accept = w == ((c + 1 + NW / 2) & (NW - 1));   // acceptance tests on row c, once, by a wave that does not publish the next row
+    if (accept) {
+      const cplx* rc = su + uoff(c);
+      const cplx piv = rc[c], ur = rc[lane >= c ? lane : c];
       const double pa = fabs(piv.x) + fabs(piv.y);
-      if ((lane > c && !(pa >= rel * (fabs(u0.x) + fabs(u0.y)))) || !(pa > 0.0)) bad = 1;
-      if (lane >= c) um = nan_max(um, u0.x * u0.x + u0.y * u0.y);
+      if ((lane > c && !(pa >= rel * (fabs(ur.x) + fabs(ur.y)))) || !(pa > 0.0)) bad = 1;
+      if (lane >= c) um = nan_max(um, ur.x * ur.x + ur.y * ur.y);
     }
+    if (w + NW * (KR - 1) > c) {                // (a wave whose rows are all finished only takes the barriers)
+    const cplx u0 = comb[(c & 1) * NB + lane];
+    const cplx u1 = lane <= c ? u0 : make_double2(0.0, 0.0);
+    const cplx* lr = lrow + (c & 1) * NB;
     // this wave's multipliers: all LDS reads issued together (inside the branches each would be waited for in turn)
     cplx fk[KR];
 #pragma unroll
-    for (int k = 0; k < KR; ++k) { const int i = w + NW * k; fk[k] = lr[i > c ? i : c]; }
+    for (int k = 0; k < KR; ++k) { const int i = w + NW * k; fk[k] = make_double2(0.0, 0.0); if (i > c) fk[k] = lr[i]; }
+#ifdef BIEM_DIAG_TRACE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    BIEM_DT(c, 2)
+#endif
 #pragma unroll
     for (int k = 0; k < KR; ++k) {
       const int i = w + NW * k;
       if (i > c) {
         a0[k] = cfnma(fk[k], u0, a0[k]);
         y1[k] = cfnma(fk[k], u1, y1[k]);
-        if (i == c + 1) publish(i, a0[k], y1[k]);
+        if (i == c + 1) { publish(i, a0[k], y1[k]); BIEM_DT(c, 3) }
       }
     }
+    }
   }
+  BIEM_DT(64, 2)
   __syncthreads();
   if (tid < NB) isq[tid] = crecip(zsqrt(su[uoff(tid) + tid]));
   block_max_publish(sqrt(um), growth + 2 * (size_t)s + 1);       // (its barrier also orders isq)
@@ -1909,12 +2028,13 @@ __global__ void __launch_bounds__(DIAG_THREADS) k_diag_utu_reg(cplx* __restrict_
   for (int r = w; r < NB; r += NW)
     if (lane >= r) Ab[(size_t)r * lda + lane] = cmul(su[uoff(r) + lane], isq[r]);
   // W[k][i] = delta_ki - (U11^{-T})[i][k] = delta_ki - L^-1[i][k] / sqrt(d_i), k <= i (lanes along i)
-  cplx* Wo = Wt + (size_t)s * NB * NB;
+  cplx* Wo = Wt + (size_t)s * w_stride;
   for (int k = w; k < NB; k += NW) {
     cplx v = make_double2(0.0, 0.0);
     if (k <= lane) { const cplx xt = cmul(sy[yoff(lane) + k], isq[lane]); v = make_double2((k == lane ? 1.0 : 0.0) - xt.x, -xt.y); }
     Wo[k * NB + lane] = v;
   }
+  BIEM_DT(64, 3)
   if (tid == 0 && bad && info[s] == 0) info[s] = -(j + 1);
 }
 
@@ -1975,15 +2095,26 @@ int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long 
   int gemm_rc = BIEM_OK;
   auto gemm = [&](auto&&... a) { const int r = launch_gemm_stream(a...); if (r != BIEM_OK && gemm_rc == BIEM_OK) gemm_rc = r; };
   const bool rhs_gemv = nrhs > 0 && nrhs <= 8;
+  // Few systems (the column-block form of the back substitution below): every panel's W = I - U11^{-T} is kept - in the panel region of
+  // the workspace, which the row form does not use: n_pad x 64 complex per system, then the solutions (nrhs x n_pad) - and the back
+  // substitution multiplies by the stored inverses instead of solving with the diagonal blocks (k_back_step).
+  const char* bf = getenv("BIEM_BACK_FORM");
+  const bool col_form = bf ? bf[0] == 'c' || bf[0] == 's' : nb <= 64;
+  const bool keep_w = col_form && nrhs > 0 && nrhs <= 3 * NB && !(bf && bf[0] == 'c');      // BIEM_BACK_FORM=col: the two-launch form (A/B)
+  cplx* Wall = (cplx*)d_work;
+  const long long wall_stride = (long long)n_pad * NB;
+  cplx* Xsol = Wall + (size_t)nb * wall_stride;
   BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_diag_utu_reg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DIAG_LDS_CPLX * sizeof(cplx))));
   auto panel = [&](int j) {
+    cplx* Wp = keep_w ? Wall + (size_t)(j / NB) * NB * NB : Wt;
+    const long long w_stride = keep_w ? wall_stride : (long long)NB * NB;
     {
       ProfScope ps(PK_PANEL, st, 0.0);
-      hipLaunchKernelGGL(k_diag_utu_reg, dim3(nb), dim3(DIAG_THREADS), DIAG_LDS_CPLX * sizeof(cplx), st, A, lda, sys_stride, j, Wt, d_info, nopiv, growth);
+      hipLaunchKernelGGL(k_diag_utu_reg, dim3(nb), dim3(DIAG_THREADS), DIAG_LDS_CPLX * sizeof(cplx), st, A, lda, sys_stride, j, Wp, w_stride, d_info, nopiv, growth);
     }
     // A operand W[k][i], i = row - j: the base shifted by -j rows (only rows j .. j+63 are addressed)
     if (n_cols > j + NB)
-      gemm(st, nb, A, lda, sys_stride, Wt - j, NB, (long long)NB * NB, j, j + NB, j + NB, n_cols, j, NB, PK_PANEL, 8.0 * (double)nb * (n_cols - j - NB) * NB * NB);
+      gemm(st, nb, A, lda, sys_stride, Wp - j, NB, w_stride, j, j + NB, j + NB, n_cols, j, NB, PK_PANEL, 8.0 * (double)nb * (n_cols - j - NB) * NB * NB);
   };
   // (A fused form - the diagonal block updated alone, then ONE pass U12 = C - [(X P^T) | W] [Q ; C] with K = 64 (q + 1) over the strip
   // instead of the pending-update pass and the solve pass - was built and measured in round 3: these passes run at the zgemm
@@ -2005,7 +2136,7 @@ int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long 
          tri_map, true);
     if (rhs_gemv) {
       ProfScope ps(PK_OTHER, st, 0.0);
-      hipLaunchKernelGGL(k_rhs_update, dim3((n_pad - (J + 4 * NB) + 255) / 256, nb, nrhs), dim3(256), 0, st, A, lda, sys_stride, strip, lda,
+      hipLaunchKernelGGL(k_rhs_update, dim3((n_pad - (J + 4 * NB) + RHS_UPD_ROWS - 1) / RHS_UPD_ROWS, nb, nrhs), dim3(256), 0, st, A, lda, sys_stride, strip, lda,
                          sys_stride, n_pad, J + 4 * NB, J, 4 * NB);
     } else if (nrhs > 0) {
       gemm(st, nb, A, lda, sys_stride, strip, lda, sys_stride, J + 4 * NB, n_pad, n_pad, n_cols, J, 4 * NB, PK_OTHER);
@@ -2019,11 +2150,19 @@ int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long 
     ProfScope ps(PK_BACK, st, 4.0 * (double)nb * n_pad * (double)n_pad * nrhs);
     const double inv_rel2 = 1.0 / (nopiv * nopiv);
     cplx* Y = (cplx*)d_work;         // the panel region of the workspace is free in the row form: room for 4 * 64 right-hand sides per system
-    const char* bf = getenv("BIEM_BACK_FORM");
     // Few systems: the row form has one workgroup per system and 64-row block (a quarter of the CUs busy at 64 systems); the
     // column-block form spreads a system's rows over workgroups (cfg 4, N = 4064: 64 systems 6.1 -> 5.1 ms, 8 systems 5.7 -> 2.6 ms,
-    // one system per call 22.8 -> 20.6 ms; at 256+ systems the row form wins: it reads U once in long runs).  BIEM_BACK_FORM=row|col forces one.
-    const bool col_form = bf ? bf[0] == 'c' : nb <= 64;
+    // one system per call 22.8 -> 20.6 ms; at 256+ systems the row form wins: it reads U once in long runs).  BIEM_BACK_FORM=row|col|step forces one.
+    if (keep_w) {
+      for (int jr = n_pad - BS; jr >= 0; jr -= BS)
+        hipLaunchKernelGGL(k_back_step, dim3(jr > 0 ? (jr + BACK_ROWS - 1) / BACK_ROWS : 1, nb), dim3(256), 0, st, A, lda, sys_stride, A + n_pad, lda,
+                           sys_stride, Wall, wall_stride, Xsol, n_pad, nrhs, jr, d_info, growth, inv_rel2);
+      hipLaunchKernelGGL(k_rhs_compact, dim3((n_pad + 255) / 256, nrhs, nb), dim3(256), 0, st, A, lda, sys_stride, Xsol, nrhs, n_pad, 1);
+      BIEM_LAUNCHCHK();
+      hipLaunchKernelGGL(k_growth_check, dim3((nb + 63) / 64), dim3(64), 0, st, nb, n_pad, growth, d_info, growth_max);
+      BIEM_LAUNCHCHK();
+      return BIEM_OK;
+    }
     if (nrhs > 4 * NB || (col_form && nrhs > 0)) {
       // (also: more right-hand sides than the compact copy of the row form holds) the column-block form on the augmented columns, same checks
       for (int jr = n_pad - BS; jr >= 0; jr -= BS) {
@@ -2164,6 +2303,31 @@ extern "C" int biem_debug_gemm(int nb, int n, int kd, int reps, unsigned long lo
   hipFree(A); hipFree(P);
   return 0;
 }
+#endif
+#ifdef BIEM_DIAG_TRACE
+extern "C" int biem_debug_diag(int reps, unsigned long long* trace_out, float* us_out) {
+  const int n = 1024; const long long lda = n + 8;
+  cplx *A = nullptr, *W = nullptr; int* info = nullptr; unsigned long long* growth = nullptr;
+  if (hipMalloc((void**)&A, (size_t)n * lda * sizeof(cplx)) != hipSuccess || hipMalloc((void**)&W, NB * NB * sizeof(cplx)) != hipSuccess ||
+      hipMalloc((void**)&info, 64) != hipSuccess || hipMalloc((void**)&growth, 64) != hipSuccess) return 1;
+  std::vector<cplx> h((size_t)n * lda);
+  for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) { const int a = r < c ? r : c, b = r < c ? c : r; h[(size_t)r * lda + c] = make_double2(r == c ? 3.0 : 0.3 * sin(0.37 * a + 1.1 * b), r == c ? 0.4 : 0.2 * cos(0.9 * a - 0.3 * b)); }
+  hipMemcpy(A, h.data(), h.size() * sizeof(cplx), hipMemcpyHostToDevice);
+  hipMemset(info, 0, 64); hipMemset(growth, 0, 64);
+  hipFuncSetAttribute((const void*)k_diag_utu_reg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DIAG_LDS_CPLX * sizeof(cplx)));
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k_diag_utu_reg, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_CPLX * sizeof(cplx), 0, A, lda, 0, 64 * r, W, (long long)NB * NB, info, 0.01, growth);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_diag_utu_reg, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_CPLX * sizeof(cplx), 0, A, lda, 0, 64 * (3 + r % 12), W, (long long)NB * NB, info, 0.01, growth);
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1); *us_out = ms * 1e3f / reps;
+  hipMemcpyFromSymbol(trace_out, HIP_SYMBOL(g_diag_trace), sizeof(unsigned long long) * 16 * 66 * 4);
+  hipFree(A); hipFree(W); hipFree(info); hipFree(growth);
+  return 0;
+}
+#endif
+#ifdef BIEM_GEMM_TRACE
 // one small update launch, as a single system sees it: C[r0 : r0 + rows, 0 : n] -= P^T M[brow ..], `reps` launches back to back; cold = 1:
 // every launch takes another row strip (the matrix is far larger than the caches), cold = 0: the same one
 extern "C" int biem_debug_gemm_strip(int n, int kd, int rows, int reps, int cold, float* us_out, int extra_cols, int col0) {
