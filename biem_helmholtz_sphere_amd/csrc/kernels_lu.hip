@@ -2038,6 +2038,164 @@ __global__ void __launch_bounds__(DIAG_THREADS) k_diag_utu_reg(cplx* __restrict_
   if (tid == 0 && bad && info[s] == 0) info[s] = -(j + 1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same diagonal block, FOUR pivots per barrier: wave w owns the four consecutive rows 4w .. 4w+3.  tools/diag_trace.cpp showed
+// the one-pivot-per-barrier form above to be a chain of latencies, not of work: per pivot a barrier, an LDS round trip, a lane
+// broadcast of the pivot (another LDS round trip), a reciprocal (rcp + two Newton steps) and the multiplier products - about a
+// dozen dependent FP64 instructions of ~20 cycles each plus ~400 cycles of LDS / barrier, ~1000 cycles where the arithmetic of a
+// step needs 250.  Here a block of four finished rows is published at once: the waves behind it apply the four rows (rank-4
+// update of their own four rows), and the wave that owns the next four rows then factors them on its own - the ten entries of its
+// 4 x 4 diagonal sub-block are broadcast ONCE (ten independent lane broadcasts in flight together), every lane runs the 4 x 4
+// elimination on them redundantly (pivots, reciprocals and the six multipliers inside the block as wave-uniform values: no further
+// broadcast), and the vector updates of the rows follow.  16 barriers and 16 broadcast round trips instead of 64 each.
+// Same arithmetic per entry as the form above (same order of the rank-1 updates), same acceptance tests, same outputs.
+// ---------------------------------------------------------------------------------------------
+constexpr int DIAGB_LDS_CPLX = 2 * (NB * (NB + 1) / 2) + NB + 2 * 2 * 4 * NB + 16;   // packed U rows, packed L^-1 rows, 1 / sqrt(d), combined rows and multipliers [2][4][64] each, the 4 x 4 sub-block
+__global__ void __launch_bounds__(1024) k_diag_utu_blk(cplx* __restrict__ A, long long lda, long long sys_stride, int j,
+                                                        cplx* __restrict__ Wt, long long w_stride, int* __restrict__ info, double rel,
+                                                        unsigned long long* __restrict__ growth) {
+  extern __shared__ cplx sd[];
+  __shared__ int bad;
+  constexpr int NW = 16, KR = 4;
+  cplx* su = sd;                                   // (r, c), c >= r, at uoff(r) + c
+  cplx* sy = su + NB * (NB + 1) / 2;               // (i, k), k <= i, at yoff(i) + k
+  cplx* isq = sy + NB * (NB + 1) / 2;              // 1 / sqrt(d_r)
+  cplx* cmb = isq + NB;                            // [2][4][64]: lane l <= i: (L^-1)_il, lane l > i: a_il of the published row i
+  cplx* mul = cmb + 2 * 4 * NB;                    // [2][4][64]: a_il / d_i
+  cplx* dsc = mul + 2 * 4 * NB;                    // [4][4]: the owner's 4 x 4 diagonal sub-block on its way to all lanes
+  auto uoff = [](int r) { return r * NB - (r * (r - 1)) / 2 - r; };
+  auto yoff = [](int i) { return (i * (i + 1)) / 2; };
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  cplx* Ab = A + (size_t)s * sys_stride + (size_t)j * lda + j;
+  if (tid == 0) bad = 0;
+  cplx a0[KR], y1[KR];
+#pragma unroll
+  for (int r = 0; r < KR; ++r) {
+    const int i = 4 * w + r;
+    a0[r] = lane >= i ? Ab[(size_t)i * lda + lane] : make_double2(0.0, 0.0);
+    y1[r] = make_double2(lane == i ? 1.0 : 0.0, 0.0);
+  }
+  // in-wave factorisation of this wave's four rows (all earlier blocks applied), then their publication
+  auto factor_block = [&]() {
+    const int i0 = 4 * w;
+    // the sub-block through LDS: four predicated writes, ten broadcast reads, one round trip (a wave's LDS operations complete in
+    // order).  Twenty ds_bpermute with a single source lane took ~1000 cycles (tools/diag_trace.cpp).
+    cplx D[KR][KR];
+    const int cl = lane - i0;
+#pragma unroll
+    for (int r = 0; r < KR; ++r) if (cl >= r && cl < KR) dsc[r * KR + cl] = a0[r];
+    // (lanes exchange data here without a workgroup barrier: the wave-scope fences keep hipcc from reading the entries before the
+    // other lanes' stores, or forwarding this lane's own store - it did, and every system failed the pivot test)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int r = 0; r < KR; ++r)
+#pragma unroll
+      for (int c = r; c < KR; ++c) D[r][c] = dsc[r * KR + c];
+#ifdef BIEM_DIAG_TRACE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    BIEM_DT(16 + w, 0)
+#endif
+    cplx ip[KR], m[KR][KR];
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+      const double rr = fast_recip(D[r][r].x * D[r][r].x + D[r][r].y * D[r][r].y);
+      const cplx dc = make_double2(D[r][r].x, -D[r][r].y);
+      ip[r] = make_double2(dc.x * rr, dc.y * rr);
+      // multipliers as (a conj d) / |d|^2: the product runs beside the reciprocal instead of behind it (two levels off the chain)
+#pragma unroll
+      for (int c = r + 1; c < KR; ++c) { const cplx t = cmul(D[r][c], dc); m[r][c] = make_double2(t.x * rr, t.y * rr); }
+#pragma unroll
+      for (int k = r + 1; k < KR; ++k)
+#pragma unroll
+        for (int c = k; c < KR; ++c) D[k][c] = cfnma(m[r][k], D[r][c], D[k][c]);
+    }
+#ifdef BIEM_DIAG_TRACE
+    asm volatile("" :: "v"(ip[3].x), "v"(ip[3].y));
+    BIEM_DT(16 + w, 1)
+#endif
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+      const cplx yr = lane <= i0 + r ? y1[r] : make_double2(0.0, 0.0);
+#pragma unroll
+      for (int k = r + 1; k < KR; ++k) { a0[k] = cfnma(m[r][k], a0[r], a0[k]); y1[k] = cfnma(m[r][k], yr, y1[k]); }
+    }
+    cplx* cb = cmb + (w & 1) * 4 * NB;
+    cplx* mb = mul + (w & 1) * 4 * NB;
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+      const int i = i0 + r;
+      cb[r * NB + lane] = make_double2(lane > i ? a0[r].x : y1[r].x, lane > i ? a0[r].y : y1[r].y);
+      mb[r * NB + lane] = cmul(a0[r], ip[r]);
+      if (lane >= i) su[uoff(i) + lane] = a0[r];
+      if (lane <= i) sy[yoff(i) + lane] = y1[r];
+    }
+    BIEM_DT(16 + w, 2)
+  };
+  if (w == 0) factor_block();
+  double um = 0.0;
+  for (int b = 0; b < NW; ++b) {
+    BIEM_DT(b, 0)
+    __syncthreads();                            // rows 4b .. 4b+3 have been published
+    BIEM_DT(b, 1)
+    if (w == ((b + 1 + NW / 2) & (NW - 1))) {   // acceptance tests on the four rows, once, by a wave far from the chain
+#pragma unroll
+      for (int r = 0; r < KR; ++r) {
+        const int c = 4 * b + r;
+        const cplx* rc = su + uoff(c);
+        const cplx piv = rc[c], ur = rc[lane >= c ? lane : c];
+        const double pa = fabs(piv.x) + fabs(piv.y);
+        if ((lane > c && !(pa >= rel * (fabs(ur.x) + fabs(ur.y)))) || !(pa > 0.0)) bad = 1;
+        if (lane >= c) um = nan_max(um, ur.x * ur.x + ur.y * ur.y);
+      }
+    }
+    if (w > b) {
+      if (w == b + 1) __builtin_amdgcn_s_setprio(3);          // the next block's owner is the dependent chain
+      const cplx* cb = cmb + (b & 1) * 4 * NB;
+      const cplx* mb = mul + (b & 1) * 4 * NB;
+      // (the reads of row r + 1 are issued before the arithmetic of row r: four exposed LDS round trips per block step otherwise)
+      cplx nu = cb[lane], nf[KR];
+#pragma unroll
+      for (int k = 0; k < KR; ++k) nf[k] = mb[4 * w + k];
+#pragma unroll
+      for (int r = 0; r < KR; ++r) {
+        const int c = 4 * b + r;
+        const cplx u0 = nu;
+        cplx fk[KR];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) fk[k] = nf[k];
+        if (r + 1 < KR) {
+          nu = cb[(r + 1) * NB + lane];
+#pragma unroll
+          for (int k = 0; k < KR; ++k) nf[k] = mb[(r + 1) * NB + 4 * w + k];
+        }
+        const cplx u1 = lane <= c ? u0 : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < KR; ++k) { a0[k] = cfnma(fk[k], u0, a0[k]); y1[k] = cfnma(fk[k], u1, y1[k]); }
+      }
+#ifdef BIEM_DIAG_TRACE
+      asm volatile("" :: "v"(a0[0].x), "v"(a0[3].y), "v"(y1[3].x));
+      BIEM_DT(b, 2)
+#endif
+      if (w == b + 1) { factor_block(); __builtin_amdgcn_s_setprio(0); }
+    }
+  }
+  __syncthreads();
+  if (tid < NB) isq[tid] = crecip(zsqrt(su[uoff(tid) + tid]));
+  block_max_publish(sqrt(um), growth + 2 * (size_t)s + 1);       // (its barrier also orders isq)
+  for (int r = w; r < NB; r += NW)
+    if (lane >= r) Ab[(size_t)r * lda + lane] = cmul(su[uoff(r) + lane], isq[r]);
+  cplx* Wo = Wt + (size_t)s * w_stride;
+  for (int k = w; k < NB; k += NW) {
+    cplx v = make_double2(0.0, 0.0);
+    if (k <= lane) { const cplx xt = cmul(sy[yoff(lane) + k], isq[lane]); v = make_double2((k == lane ? 1.0 : 0.0) - xt.x, -xt.y); }
+    Wo[k * NB + lane] = v;
+  }
+  if (tid == 0 && bad && info[s] == 0) info[s] = -(j + 1);
+}
+
 bool sym_small_path(int n_active, int nrhs) {
   return n_active > 0 && n_active <= SMALL_N_MAX && nrhs <= SMALL_RHS_MAX && n_active + nrhs <= 128 && small_utu_lds(n_active, nrhs) <= 160 * 1024 - 2048 &&
          !getenv("BIEM_NO_SMALL_PATH");
@@ -2100,17 +2258,23 @@ int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long 
   // substitution multiplies by the stored inverses instead of solving with the diagonal blocks (k_back_step).
   const char* bf = getenv("BIEM_BACK_FORM");
   const bool col_form = bf ? bf[0] == 'c' || bf[0] == 's' : nb <= 64;
-  const bool keep_w = col_form && nrhs > 0 && nrhs <= 3 * NB && !(bf && bf[0] == 'c');      // BIEM_BACK_FORM=col: the two-launch form (A/B)
+  // (every workgroup of a block step forms x_b for itself from the 64 KB inverse: a latency trade that pays for a handful of systems -
+  // at 64 systems of cfg 4 the back substitution went from 4.4 to 11.5 ms with it; BIEM_BACK_FORM=step forces it, =col the two-launch form)
+  const bool keep_w = col_form && nrhs > 0 && nrhs <= 3 * NB && (bf ? bf[0] == 's' : nb <= 8);
   cplx* Wall = (cplx*)d_work;
   const long long wall_stride = (long long)n_pad * NB;
   cplx* Xsol = Wall + (size_t)nb * wall_stride;
   BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_diag_utu_reg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DIAG_LDS_CPLX * sizeof(cplx))));
+  BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_diag_utu_blk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DIAGB_LDS_CPLX * sizeof(cplx))));
+  const char* dform = getenv("BIEM_DIAG_FORM");                  // step: one pivot per barrier (the A/B of the tests); default: four
+  const bool diag_blk = !(dform && dform[0] == 's');
   auto panel = [&](int j) {
     cplx* Wp = keep_w ? Wall + (size_t)(j / NB) * NB * NB : Wt;
     const long long w_stride = keep_w ? wall_stride : (long long)NB * NB;
     {
       ProfScope ps(PK_PANEL, st, 0.0);
-      hipLaunchKernelGGL(k_diag_utu_reg, dim3(nb), dim3(DIAG_THREADS), DIAG_LDS_CPLX * sizeof(cplx), st, A, lda, sys_stride, j, Wp, w_stride, d_info, nopiv, growth);
+      if (diag_blk) hipLaunchKernelGGL(k_diag_utu_blk, dim3(nb), dim3(1024), DIAGB_LDS_CPLX * sizeof(cplx), st, A, lda, sys_stride, j, Wp, w_stride, d_info, nopiv, growth);
+      else hipLaunchKernelGGL(k_diag_utu_reg, dim3(nb), dim3(DIAG_THREADS), DIAG_LDS_CPLX * sizeof(cplx), st, A, lda, sys_stride, j, Wp, w_stride, d_info, nopiv, growth);
     }
     // A operand W[k][i], i = row - j: the base shifted by -j rows (only rows j .. j+63 are addressed)
     if (n_cols > j + NB)
@@ -2316,10 +2480,18 @@ extern "C" int biem_debug_diag(int reps, unsigned long long* trace_out, float* u
   hipMemset(info, 0, 64); hipMemset(growth, 0, 64);
   hipFuncSetAttribute((const void*)k_diag_utu_reg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DIAG_LDS_CPLX * sizeof(cplx)));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k_diag_utu_reg, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_CPLX * sizeof(cplx), 0, A, lda, 0, 64 * r, W, (long long)NB * NB, info, 0.01, growth);
+  const bool blk = getenv("BIEM_DIAG_FORM") == nullptr;
+  hipFuncSetAttribute((const void*)k_diag_utu_blk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(DIAGB_LDS_CPLX * sizeof(cplx)));
+  for (int r = 0; r < 3; ++r) {
+    if (blk) hipLaunchKernelGGL(k_diag_utu_blk, dim3(1), dim3(1024), DIAGB_LDS_CPLX * sizeof(cplx), 0, A, lda, 0, 64 * r, W, (long long)NB * NB, info, 0.01, growth);
+    else hipLaunchKernelGGL(k_diag_utu_reg, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_CPLX * sizeof(cplx), 0, A, lda, 0, 64 * r, W, (long long)NB * NB, info, 0.01, growth);
+  }
   hipDeviceSynchronize();
   hipEventRecord(e0, 0);
-  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_diag_utu_reg, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_CPLX * sizeof(cplx), 0, A, lda, 0, 64 * (3 + r % 12), W, (long long)NB * NB, info, 0.01, growth);
+  for (int r = 0; r < reps; ++r) {
+    if (blk) hipLaunchKernelGGL(k_diag_utu_blk, dim3(1), dim3(1024), DIAGB_LDS_CPLX * sizeof(cplx), 0, A, lda, 0, 64 * (3 + r % 12), W, (long long)NB * NB, info, 0.01, growth);
+    else hipLaunchKernelGGL(k_diag_utu_reg, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_CPLX * sizeof(cplx), 0, A, lda, 0, 64 * (3 + r % 12), W, (long long)NB * NB, info, 0.01, growth);
+  }
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms = 0; hipEventElapsedTime(&ms, e0, e1); *us_out = ms * 1e3f / reps;
   hipMemcpyFromSymbol(trace_out, HIP_SYMBOL(g_diag_trace), sizeof(unsigned long long) * 16 * 66 * 4);
