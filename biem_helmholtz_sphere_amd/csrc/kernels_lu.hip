@@ -1216,23 +1216,15 @@ __global__ void __launch_bounds__(256) k_back_step(const cplx* __restrict__ A, l
   cplx wr[16];
 #pragma unroll
   for (int kk = 0; kk < 16; ++kk) { const int k = wave * 16 + kk; wr[kk] = lane >= k ? Wb[k * NB + lane] : make_double2(0.0, 0.0); }
-  {
-    double um2 = 0.0;
-    bool badm = false;
+  // (all loads of the prologue are issued together: the right-hand side's block, the diagonal entries of the checks)
+  cplx ynext = threadIdx.x < BS ? Fs[(size_t)(jr + threadIdx.x) * ldf] : make_double2(0.0, 0.0);
+  cplx dg[BACK_ROWS / 4];
 #pragma unroll
-    for (int k = 0; k < BACK_ROWS / 4; ++k) {
-      if (i0 + k >= jr) break;
-      const cplx d = As[(size_t)(i0 + k) * lda + i0 + k];
-      const double m2 = u[k].x * u[k].x + u[k].y * u[k].y, d2 = d.x * d.x + d.y * d.y;
-      if (!(m2 <= inv_rel2 * d2)) badm = true;
-      um2 = nan_max(um2, m2 * d2);
-    }
-    block_max_publish(sqrt(um2), growth + 2 * (size_t)s + 1);
-    if (badm && info[s] == 0) info[s] = -((i0 / NB) * NB + 1);
-  }
+  for (int k = 0; k < BACK_ROWS / 4; ++k) dg[k] = (i0 + k < jr) ? As[(size_t)(i0 + k) * lda + i0 + k] : make_double2(1.0, 0.0);
   for (int q = 0; q < nrhs; ++q) {
     __syncthreads();
-    if (threadIdx.x < BS) syb[threadIdx.x] = Fs[(size_t)(jr + threadIdx.x) * ldf + q];
+    if (threadIdx.x < BS) syb[threadIdx.x] = ynext;
+    if (q + 1 < nrhs && threadIdx.x < BS) ynext = Fs[(size_t)(jr + threadIdx.x) * ldf + q + 1];
     __syncthreads();
     const cplx yl = syb[lane];
 #pragma unroll
@@ -1259,6 +1251,19 @@ __global__ void __launch_bounds__(256) k_back_step(const cplx* __restrict__ A, l
         *y = t;
       }
     }
+  }
+  {   // the checks of the entries this workgroup read, behind the arithmetic the next launch waits for
+    double um2 = 0.0;
+    bool badm = false;
+#pragma unroll
+    for (int k = 0; k < BACK_ROWS / 4; ++k) {
+      if (i0 + k >= jr) break;
+      const double m2 = u[k].x * u[k].x + u[k].y * u[k].y, d2 = dg[k].x * dg[k].x + dg[k].y * dg[k].y;
+      if (!(m2 <= inv_rel2 * d2)) badm = true;
+      um2 = nan_max(um2, m2 * d2);
+    }
+    block_max_publish(sqrt(um2), growth + 2 * (size_t)s + 1);
+    if (badm && info[s] == 0) info[s] = -((i0 / NB) * NB + 1);
   }
 }
 
