@@ -1,5 +1,5 @@
 #!/bin/bash
-# full GPU suite + bench lines of all configurations (single_system_ms of 1, 2, 4; headline of 3)
+# full GPU suite + bench lines of all configurations without the CPU baseline (a quick check of a build on one box)
 O=gpurun_out/r03_eval; mkdir -p $O
 timeout -k 10 1000 python -m pytest tests -m gpu -q > $O/t_full.log 2>&1; echo "tests exit $?"; tail -3 $O/t_full.log
 for cfg in 1 2 4 5; do

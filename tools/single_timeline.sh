@@ -1,4 +1,6 @@
 #!/bin/bash
+# kernel timelines of one system per call (tools/single_timeline.py) on the GPU box: CFGS="1 2 3 4" LINES_SHOWN=14 bash tools/single_timeline.sh
+# (also runs tools/gemm_small when it has been built: the small update launches alone)
 O=gpurun_out/r03_single; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 [ -x $R/tools/gemm_small ] && timeout -k 10 120 $R/tools/gemm_small 4096
