@@ -202,6 +202,7 @@ class _Plan:
         w = np.zeros(self.Q)
         L.check(lib.biem_plan_quadrature(h, y.ctypes.data, w.ctypes.data))
         self.quad_y = torch.as_tensor(y, device=dev)          # [Q, d] unit vectors
+        self.y_by_axes: dict = {}                              # the same, [d, ...(quadrature axes)] per axis order of the caller's tree
         lab = np.zeros((self.H, 3), dtype=np.int32)
         deg = np.zeros(self.H, dtype=np.int32)
         L.check(lib.biem_plan_labels(h, lab.ctypes.data, deg.ctypes.data))
@@ -441,8 +442,17 @@ def _warn_biem_inputs(k: Any, eta: Any) -> None:
     k and eta may mix torch tensors (any device), NumPy arrays, lists and scalars.  (The reference's own test of the second
     one, :278-280, guards the Im k term with "eta is not castable to float64", which is never true once the complex-eta check
     above it has passed, so there only eta Re k < 0 can fire; here the condition the message states is checked.)"""
-    k_h = _host_array(k)
-    eta_h = None if eta is None else _host_array(eta)
+    if isinstance(k, torch.Tensor) and isinstance(eta, torch.Tensor) and k.is_cuda and eta.is_cuda and k.device == eta.device:
+        # both on one GPU: ONE device -> host copy (each copy is a synchronisation; a call with one small system pays for every one)
+        nk = k.numel()
+        buf = torch.cat([k.detach().reshape(-1).to(torch.complex128), eta.detach().reshape(-1).to(torch.complex128)]).cpu().numpy()
+        k_h = buf[:nk].reshape(tuple(k.shape))
+        if not k.is_complex():
+            k_h = k_h.real
+        eta_h = buf[nk:].real.reshape(tuple(eta.shape))
+    else:
+        k_h = _host_array(k)
+        eta_h = None if eta is None else _host_array(eta)
     if eta_h is not None and bool(np.any(eta_h == 0)):
         warnings.warn(
             "The solution may be incorrect"
@@ -530,9 +540,13 @@ def _boundary_samples(plan: _Plan, origin: _Origin, fl: _Flat, batch, uin, uin_g
     inv = [0] * d
     for i, pi_ in enumerate(perm):
         inv[pi_] = i
-    y = plan.quad_y.T[inv].reshape((d,) + qshape)                      # (d, ...(f)), original axes
+    ident = inv == list(range(d))                                      # (no primed nodes: no gather kernels for the axis order)
+    ykey = tuple(inv)
+    y = plan.y_by_axes.get(ykey)
+    if y is None:
+        y = plan.y_by_axes[ykey] = (plan.quad_y.T if ident else plan.quad_y.T[inv]).reshape((d,) + qshape).contiguous()   # (d, ...(f)), original axes
     x_rel = y[(...,) + (None,) * (nbt + 1)]                            # (d, ...(f), 1.., 1)
-    cen = fl.centers[..., inv].reshape(((nb,) if fl.geom_batched else (1,)) + (B, d))
+    cen = (fl.centers if ident else fl.centers[..., inv]).reshape(((nb,) if fl.geom_batched else (1,)) + (B, d))
     rad = fl.radii.reshape(((nb,) if fl.geom_batched else (1,)) + (B,))
     if fl.geom_batched:
         cen = cen.reshape(tuple(batch) + (B, d))
@@ -552,13 +566,21 @@ def _boundary_samples(plan: _Plan, origin: _Origin, fl: _Flat, batch, uin, uin_g
         t = t.reshape(((nb,) if fl.ab_batched else (1,)) + (B,))
         t = t.reshape((tuple(batch) if fl.ab_batched else (1,) * nbt) + (B,))
         return torch.movedim(t, -1, 0)[(None,) * len(qshape)]       # (1.., B, ...batch)
-    g = torch.zeros(qshape + (B,) + tuple(batch), dtype=torch.complex128, device=dev)
+    g = None
     if uin is not None:
         u = _to_dev(uin(xu), dev, torch.complex128)
-        g = g - ab(fl.alpha) * u
+        g = (ab(fl.alpha) * u).neg_()                                  # (a fresh tensor: negated in place)
     if uin_grad is not None:
         gu = _to_dev(uin_grad(xu), dev, torch.complex128)
-        g = g - ab(fl.beta) * torch.sum(gu * x_rel.to(torch.complex128), dim=0)
+        t = ab(fl.beta) * torch.sum(gu * x_rel.to(torch.complex128), dim=0)
+        g = t.neg_() if g is None else g - t
+    lead = qshape + (B,) + tuple(batch)
+    if g is None:
+        g = torch.zeros(lead, dtype=torch.complex128, device=dev)
+    else:
+        tgt = tuple(torch.broadcast_shapes(tuple(g.shape), lead))       # (a callable that returned fewer / shorter axes than it was given)
+        if tuple(g.shape) != tgt:
+            g = g.expand(tgt)
     # The incident field may vary along batch axes on which the operator (k, eta, geometry, alpha, beta) has size 1
     # (e.g. many incidence directions for one wavenumber): those axes become right-hand sides of ONE factorisation.
     # The reference broadcasts the matrix over them in btensorsolve (_biem.py:797), i.e. factors it again per incidence.
@@ -629,7 +651,7 @@ def biem(
     ndim_first = k_t.ndim
     plan = _plan(tree, n_end, dev)
     H, Q = plan.H, plan.Q
-    fl = _flatten(batch, B, centers_t[..., list(perm)], radii_t, k_t, eta_t, alpha_t, beta_t)
+    fl = _flatten(batch, B, centers_t if list(perm) == list(range(len(perm))) else centers_t[..., list(perm)], radii_t, k_t, eta_t, alpha_t, beta_t)
     nb = fl.nb
     sp = _stream_ptr(dev)
 
