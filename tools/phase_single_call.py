@@ -1,4 +1,5 @@
-"""Host-side phases of ONE small biem() call (cfg 1): time inside the argument checks, the boundary samples, the C entry point and the\ndevice -> host copies (each one a synchronisation).  python tools/phase_single_call.py   (needs a GPU)"""
+"""Host-side phases of ONE small biem() call (cfg 1): time inside the argument checks, the boundary samples, the C entry point and the
+device -> host copies (each one a synchronisation).  python tools/phase_single_call.py   (needs a GPU)"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
