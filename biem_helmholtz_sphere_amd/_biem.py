@@ -56,6 +56,7 @@ def _harm_n_ndim_le(n_end: int, c_ndim: int) -> int:
 
 
 _last_solve_stats: dict = {}   # how the last biem() call solved its systems (tests / bench)
+_ws_memo: dict = {}            # device -> (shape key of the last solve, its workspace bytes): see biem()
 
 
 def max_memory(*, c_ndim: int, n_end: int, n_balls: int) -> int:
@@ -658,6 +659,19 @@ def biem(
     has_rhs = not (uin is None and uin_grad is None)
     g = None
     full, op_axes, rhs_axes, nrhs = tuple(batch), list(range(len(batch))), [], 1
+    # A repeated call of the same shape takes its workspace FIRST, before the boundary samples: the block the previous call
+    # returned to torch's caching allocator is then still whole.  Taken after them, one of their mid-size temporaries may have
+    # been carved out of it - and a second block of that size need not exist (cfg 3's whole batch: 164 of 288 GB).
+    ws_key = (tree, int(n_end), int(nb), int(B), int(chunk), os.environ.get("BIEM_MAX_RESIDENT_BYTES"))
+    work_pre = None
+    if has_rhs and nb > 0 and (B > 1 or force_matrix):
+        memo = _ws_memo.get(dev)
+        if memo is not None and memo[0] == ws_key:
+            try:
+                with torch.cuda.device(dev):
+                    work_pre = torch.empty(memo[1], dtype=torch.uint8, device=dev)
+            except torch.OutOfMemoryError:
+                work_pre = None
     if has_rhs:
         # (the all-zero tests are only needed when the matching callable is missing; Python scalars are decided on the host)
         def _all_zero(v, v_t):
@@ -697,13 +711,24 @@ def biem(
                 else:
                     free, _total = torch.cuda.mem_get_info(dev)
                     avail = free + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+                    if work_pre is not None:
+                        avail += int(work_pre.numel())     # (the block taken in advance above is this call's own)
                     budget = int(0.85 * avail)
                     cap = os.environ.get("BIEM_MAX_RESIDENT_BYTES")      # a drop-in inside a larger torch program: bound the workspace
                     if cap:
                         budget = min(budget, max(int(float(cap)), per))
                     chunk = max(1, min(nb, 32768, budget // per))      # 32768: grid dimension of the per-system kernels
             wbytes = int(lib.biem_solve_workspace_bytes(plan.handle, nb, B, nrhs, chunk))
-            work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+            if work_pre is not None and work_pre.numel() == wbytes:
+                work = work_pre
+            else:
+                work_pre = None                    # (another size after all: back to the allocator before the right one is taken)
+                try:
+                    work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+                except torch.OutOfMemoryError:
+                    torch.cuda.empty_cache()       # cached blocks of other sizes (an earlier, different job): released, one more attempt
+                    work = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+            _ws_memo[dev] = (ws_key, wbytes)
             density_t = torch.empty((nb, nrhs, B, H), dtype=torch.complex128, device=dev)
             info = torch.zeros(nb, dtype=torch.int32, device=dev)
             # The equilibrated system is complex symmetric in a real-harmonic basis (include/biem_mi355.h, biem_solve_ldlt):

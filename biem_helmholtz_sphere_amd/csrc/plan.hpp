@@ -71,6 +71,7 @@ struct biem_plan {
   std::vector<uint16_t> rphsel;             // [U U][2]: phase selector of list A, of list B: 2 * phase id + (1: conjugate phase)
   std::vector<int> rchunk, rcrow, rwrow;
   int rchunk_rows_max = 0;
+  double red_gather_cycles = 0.0;           // LDS cycles per row and ds_read_b128 lane group of the table gather (1 = conflict-free)
   // the same lists cut into small chunks for the systems-in-lanes form of the symmetric fill (k_fill_sys: no LDS ceiling on H2)
   std::vector<int> schunk;
   int schunk_terms_max = 0, schunk_pairs_max = 0;
