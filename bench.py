@@ -213,6 +213,8 @@ def main() -> int:
     ap.add_argument("--cpu-baseline-systems", type=int, default=4)
     ap.add_argument("--cpu-baseline-reps", type=int, default=5, help="BASELINE.md section 3: median of 5 repetitions after one warm-up")
     ap.add_argument("--sym-vs-lu-systems", type=int, default=16, help="systems of the timed batch re-solved with the pivoted LU for the whole-batch accuracy figure")
+    ap.add_argument("--single-system", action="store_true", help="also for cfg 3 / 5 (batches of different systems): latency of the first system alone, one system per call (default only for the one-system configs 1, 2, 4: its small launches would enter a profiler's per-kernel averages of the default run)")
+    ap.add_argument("--no-single-system", action="store_true", help="skip the one-system-per-call latency measurement")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -334,9 +336,9 @@ def main() -> int:
     N = w["B"] * H
     solver = os.environ.get("BIEM_SOLVER", "ldlt")
 
-    # latency of a single system per call (what the reference's own drivers do; for cfg 3 / 5 the first system of the batch), rank 0 only
+    # latency of a single system per call (what the reference's own drivers do; cfg 3 / 5 - the first system of the batch - with --single-system), rank 0 only
     single_ms = None
-    if rank == 0:
+    if rank == 0 and not args.no_single_system and (cfg in (1, 2, 4) or args.single_system):
         u1, g1 = amd.plane_wave(k=k_t[:1], direction=t(dirs[:, :1]))
         kw1 = dict(kw)
         if w["beta"] != 0:
