@@ -527,8 +527,10 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
                   for (uint16_t cix : chosen) if (cix == tl[best].second) { shared = true; break; }
                   if (!shared) { chosen.push_back(tl[best].second); ++load[tl[best].second & 15]; }
                 }
-                // lanes without a term in this row read an entry somebody else of the group reads anyway (coefficient 0)
-                const uint16_t filler = chosen.empty() ? (uint16_t)0 : chosen[0];
+                // lanes without a term in this row (coefficient 0) read an entry somebody else of the group reads anyway: the one of
+                // the lowest degree (T' is degree-major: the smallest index; entry 0 itself, h_0, was the padding before)
+                uint16_t filler = 0;
+                if (!chosen.empty()) { filler = chosen[0]; for (uint16_t cix : chosen) if (cix < filler) filler = cix; }
                 for (int q = 0; q < 16; ++q) if (rowterm[t][kB128Group[g][q]].second == 0xffff) rowterm[t][kB128Group[g][q]] = std::make_pair(0.0, filler);
               }
             }
