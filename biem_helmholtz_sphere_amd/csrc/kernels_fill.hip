@@ -762,7 +762,7 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
                                                                 const int* __restrict__ spos, const int* __restrict__ rchunk,
                                                                 const int* __restrict__ rcrow, const int* __restrict__ rwrow, int rows_max,
                                                                 const double* __restrict__ rcoef, const uint16_t* __restrict__ ridx,
-                                                                const uint16_t* __restrict__ rphsel, const int* __restrict__ rpair,
+                                                                const uint16_t* __restrict__ rphsel,
                                                                 const cplx* __restrict__ T,
                                                                 cplx* __restrict__ A, long long lda, long long sys_stride,
                                                                 const int* __restrict__ classes) {
@@ -787,11 +787,8 @@ __global__ void __launch_bounds__(FILL_SYM_THREADS) k_fill_red(int H, int U, int
   }
   // this thread's unit pair (fixed for the whole kernel): slots, degrees, phase selectors and the offsets of its (up to) four
   // entries inside a block, so that a combination's stores need no 64-bit multiplications
-  // (the chunk's slots p0 .. p1-1 are waves of 64; which unit pair a lane works on comes from the plan's schedule: segments of 8
-  // consecutive columns of a row of the unit-pair grid, sorted by list length - plan.cpp; -1 = idle lane)
-  const int pi_s = tid < npr ? rpair[p0 + tid] : -1;
-  const bool active = pi_s >= 0;
-  const int pi = active ? pi_s : 0;
+  const bool active = tid < npr;
+  const int pi = p0 + (active ? tid : 0);
   const int u = pi / U, v = pi - u * U;
   const int rh = units[2 * u], rp = units[2 * u + 1], ch = units[2 * v], cp = units[2 * v + 1];
   const bool r2 = rp != rh, c2 = cp != ch;                 // two rows / two columns in this block
@@ -1354,7 +1351,7 @@ int launch_fill_sym(const biem_plan* p, int nb, int B, const double* d_k, const 
     BIEM_HIPCHK(hipFuncSetAttribute((const void*)k_fill_red<KT, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));              \
     hipLaunchKernelGGL((k_fill_red<KT, NC>), dim3(nchunks, (unsigned)gy), dim3(red_threads), shm, st, H, U, HR, p->E, p->NP, p->n_end, B, nb, npairs, \
                        p->d_deg, p->d_units, p->d_spos, p->d_rchunk, p->d_rcrow, p->d_rwrow, p->rchunk_rows_max, p->d_rcoef, p->d_ridx,   \
-                       p->d_rphsel, p->d_rpair, T, (cplx*)d_A, lda, sys_stride, classes);                                                 \
+                       p->d_rphsel, T, (cplx*)d_A, lda, sys_stride, classes);                                                             \
   }
     if (use_red) {
       // two combinations per iteration (the plan reserves LDS for two table rows) unless BIEM_FILL_NC=1 at plan build (A / B runs)

@@ -449,63 +449,14 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
         if (crows > p->rchunk_rows_max) p->rchunk_rows_max = (int)crows;
         crows = 0; cw = 0; wr.assign(33, 0);
       };
-      // Which unit pairs share a wave.  A wave's lists are padded to its longest and a chunk's waves wait for its slowest, so the
-      // pairs are grouped by list length - but in SEGMENTS of 8 consecutive columns of one row of the unit-pair grid, so that a
-      // segment's stores stay 128 contiguous bytes per matrix row: segments sorted by (length of list A, of list B), 8 segments per
-      // wave, waves in that order into the chunks (rpair: scheduled slot -> unit pair, -1 = idle lane).  Rows padded per term
-      // 1.66 -> 1.46 at cfg 3, 2.13 -> 1.72 at cfg 5; waves of a chunk within 1 % of its longest (89 / 83 % before).
-      // BIEM_FILL_WAVE_ORDER=natural keeps the segments in grid order (A/B).
-      auto pair_lists = [&](long long pi, size_t& ea, size_t& eb, bool& hb) {
-        const int u = (int)(pi / U), v = (int)(pi - (long long)u * U);
-        const int h = p->units[2 * u], pp = p->units[2 * u + 1], ch = p->units[2 * v], cp = p->units[2 * v + 1];
-        ea = (size_t)h * H + ch; eb = (size_t)h * H + cp; hb = (pp != h) && (cp != ch);
-      };
-      struct Seg { long long first; int count; uint32_t la, lb; };
-      std::vector<Seg> segs;
-      for (int u = 0; lists && u < U; ++u)
-        for (int v0 = 0; v0 < U; v0 += 8) {
-          Seg sg; sg.first = (long long)u * U + v0; sg.count = U - v0 < 8 ? U - v0 : 8; sg.la = 0; sg.lb = 0;
-          for (int q = 0; q < sg.count; ++q) {
-            size_t ea, eb; bool hb; pair_lists(sg.first + q, ea, eb, hb);
-            const uint32_t la = p->ptr[ea + 1] - p->ptr[ea], lb = hb ? p->ptr[eb + 1] - p->ptr[eb] : 0;
-            if (la > sg.la) sg.la = la;
-            if (lb > sg.lb) sg.lb = lb;
-          }
-          segs.push_back(sg);
-        }
-      { const char* ewo = getenv("BIEM_FILL_WAVE_ORDER");
-        if (ewo && ewo[0] == 's')
-          std::stable_sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return a.lb != b.lb ? a.lb > b.lb : a.la > b.la; }); }
-      p->rpair.clear();
-      const long long n_sched = (long long)((segs.size() + 7) / 8) * 64;
-      // the waves (8 consecutive segments of that order) go into the chunks by their total number of rows
-      std::vector<size_t> worder((size_t)(n_sched / 64));
-      {
-        std::vector<uint32_t> wrows(worder.size(), 0);
-        for (size_t wv = 0; wv < worder.size(); ++wv) {
-          uint32_t la = 0, lb = 0;
-          for (size_t si = wv * 8; si < wv * 8 + 8 && si < segs.size(); ++si) { if (segs[si].la > la) la = segs[si].la; if (segs[si].lb > lb) lb = segs[si].lb; }
-          wrows[wv] = ((la + 3) & ~3u) + ((lb + 3) & ~3u);
-          worder[wv] = wv;
-        }
-        const char* ewo = getenv("BIEM_FILL_WAVE_ORDER");
-        if (!(ewo && ewo[0] == 'n')) std::stable_sort(worder.begin(), worder.end(), [&](size_t a, size_t b) { return wrows[a] > wrows[b]; });
-      }
-      for (long long w0 = 0; w0 < n_sched && rok; w0 += 64) {
-        long long lane_pair[64];
-        for (int sgi = 0; sgi < 8; ++sgi) {
-          const size_t si = worder[(size_t)(w0 / 64)] * 8 + sgi;
-          for (int q = 0; q < 8; ++q) lane_pair[8 * sgi + q] = (si < segs.size() && q < segs[si].count) ? segs[si].first + q : -1;
-        }
-        for (int i = 0; i < 64; ++i) p->rpair.push_back((int32_t)lane_pair[i]);
-        const int nl = 64;
+      for (long long w0 = 0; w0 < total_pairs && rok; w0 += 64) {
+        const int nl = (int)((total_pairs - w0 < 64) ? total_pairs - w0 : 64);
         size_t eA[64], eB[64]; bool hasB[64];
         uint32_t LA = 0, LB = 0;
         for (int i = 0; i < nl; ++i) {
-          eA[i] = 0; eB[i] = 0; hasB[i] = false;
-          const long long pi = lane_pair[i];
-          if (pi < 0) continue;
-          pair_lists(pi, eA[i], eB[i], hasB[i]);
+          const long long pi = w0 + i; const int u = (int)(pi / U), v = (int)(pi - (long long)u * U);
+          const int h = p->units[2 * u], pp = p->units[2 * u + 1], ch = p->units[2 * v], cp = p->units[2 * v + 1];
+          eA[i] = (size_t)h * H + ch; eB[i] = (size_t)h * H + cp; hasB[i] = (pp != h) && (cp != ch);
           uint16_t sA = 0, sB = 0;
           rok = rok && list_sel(eA[i], sA);
           if (hasB[i]) rok = rok && list_sel(eB[i], sB);
@@ -532,7 +483,7 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
           // bank conflicts (profiles/r03_pmc_summary.txt).  BIEM_FILL_LIST_ORDER=natural keeps the natural order (A/B).
           std::vector<std::vector<std::pair<double, uint16_t>>> terms(64);
           for (int i = 0; i < nl; ++i)
-            if (lane_pair[i] >= 0 && (pass == 0 || hasB[i])) {
+            if (pass == 0 || hasB[i]) {
               const size_t e = pass ? eB[i] : eA[i];
               for (uint32_t q = p->ptr[e]; q < p->ptr[e + 1]; ++q) terms[i].push_back(std::make_pair(p->coef[q], (uint16_t)p->red_of[p->tidx[q]]));
             }
@@ -611,11 +562,11 @@ int plan_build_host(biem_plan* p, int tree, int n_end) {
         }
         crows += LA + LB; ++cw;
       }
-      if (rok && cw > 0) close_chunk(n_sched);
+      if (rok && cw > 0) close_chunk(total_pairs);
       p->red_gather_cycles = gather_groups > 0 ? (double)gather_cycles / (double)gather_groups : 0.0;
       if (getenv("BIEM_PLAN_STATS")) fprintf(stderr, "plan tree %d n_end %d: table gather %.3f LDS cycles per row and lane group (1 = conflict-free), %lld rows\n", tree, n_end, p->red_gather_cycles, gather_groups / 4);
       p->red_lists_ok = rok && (int)p->rchunk.size() > 1;
-      if (!p->red_lists_ok) { p->rcoef.clear(); p->ridx.clear(); p->rpair.clear(); p->rchunk.assign(1, 0); p->rcrow.assign(1, 0); p->rwrow.clear(); p->rchunk_rows_max = 0; }
+      if (!p->red_lists_ok) { p->rcoef.clear(); p->ridx.clear(); p->rchunk.assign(1, 0); p->rcrow.assign(1, 0); p->rwrow.clear(); p->rchunk_rows_max = 0; }
     }
     // chunks: the paired pair table (H2lin complex), the per-degree factors of two balls, the list pointers and the term slice share LDS
     const int max_pairs = 1024;                                    // = FILL_SYM_THREADS: one unit pair per thread
@@ -699,7 +650,6 @@ int plan_upload(biem_plan* p) {
   if ((rc = up(&p->d_ph_mu, p->ph_mu))) return rc;
   if ((rc = up(&p->d_rcoef, p->rcoef))) return rc;
   if ((rc = up(&p->d_ridx, p->ridx))) return rc;
-  if ((rc = up(&p->d_rpair, p->rpair))) return rc;
   if ((rc = up(&p->d_rphsel, p->rphsel))) return rc;
   if ((rc = up(&p->d_rchunk, p->rchunk))) return rc;
   if ((rc = up(&p->d_rcrow, p->rcrow))) return rc;
@@ -717,7 +667,7 @@ void plan_free(biem_plan* p) {
     (void)hipFree(p->d_qchunk); (void)hipFree(p->d_schunk);
     (void)hipFree(p->d_lin2); (void)hipFree(p->d_q2ptr); (void)hipFree(p->d_q2coef); (void)hipFree(p->d_q2idx16);
     (void)hipFree(p->d_red_of); (void)hipFree(p->d_red_first); (void)hipFree(p->d_red_label); (void)hipFree(p->d_ph_mu);
-    (void)hipFree(p->d_rcoef); (void)hipFree(p->d_ridx); (void)hipFree(p->d_rpair); (void)hipFree(p->d_rphsel); (void)hipFree(p->d_rchunk); (void)hipFree(p->d_rcrow); (void)hipFree(p->d_rwrow);
+    (void)hipFree(p->d_rcoef); (void)hipFree(p->d_ridx); (void)hipFree(p->d_rphsel); (void)hipFree(p->d_rchunk); (void)hipFree(p->d_rcrow); (void)hipFree(p->d_rwrow);
   }
   delete p;
 }

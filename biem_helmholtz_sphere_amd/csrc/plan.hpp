@@ -68,7 +68,6 @@ struct biem_plan {
   int red_waves = 16, red_nc = 2;           // workgroup of k_fill_red (waves) and combinations per iteration the chunks were cut for (experiments: BIEM_FILL_RED_WAVES=8, BIEM_FILL_NC=1 at plan build)
   std::vector<double> rcoef;                // [rows][64]
   std::vector<uint16_t> ridx;               // [rows][64] indices e into T'
-  std::vector<int32_t> rpair;               // [scheduled slots]: unit pair u U + v of the lane (64 per wave; -1: idle lane); chunk c = slots [rchunk[c], rchunk[c+1])
   std::vector<uint16_t> rphsel;             // [U U][2]: phase selector of list A, of list B: 2 * phase id + (1: conjugate phase)
   std::vector<int> rchunk, rcrow, rwrow;
   int rchunk_rows_max = 0;
@@ -88,7 +87,6 @@ struct biem_plan {
   int* d_qchunk = nullptr; int* d_schunk = nullptr;
   int* d_lin2 = nullptr; uint32_t* d_q2ptr = nullptr; double* d_q2coef = nullptr; uint16_t* d_q2idx16 = nullptr;
   int* d_red_of = nullptr; int* d_red_first = nullptr; int* d_red_label = nullptr; int* d_ph_mu = nullptr;
-  int32_t* d_rpair = nullptr;
   double* d_rcoef = nullptr; uint16_t* d_ridx = nullptr; uint16_t* d_rphsel = nullptr; int* d_rchunk = nullptr; int* d_rcrow = nullptr; int* d_rwrow = nullptr;
 };
 
