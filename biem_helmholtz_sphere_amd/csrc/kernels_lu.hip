@@ -2290,6 +2290,21 @@ int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long 
   // pipeline's rate per K-chunk like the bulk update (0.445 / 0.79 / 1.22 ms for K = 64 / 128 / 192 at cfg 3), not at a bandwidth
   // limit, so the same K-chunks in fewer passes gain 2.5 % of panel + in-group time at cfg 3, nothing at cfg 5, and lose 27 % at
   // cfg 4 and 30 % for one system per call (three more small launches per panel).  Not kept)
+  // second stream + two events for the right-hand sides' update beside the K = 256 update (below); the stream lives per device
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  { const char* es = getenv("BIEM_RHS_SIDE_STREAM");
+    if (rhs_gemv && n_pad > 4 * NB && !(es && es[0] == '0')) {
+      static hipStream_t side_of[64] = {nullptr};
+      int devid = 0;
+      if (hipGetDevice(&devid) == hipSuccess && devid >= 0 && devid < 64) {
+        if (side_of[devid] == nullptr && hipStreamCreateWithFlags(&side_of[devid], hipStreamNonBlocking) != hipSuccess) side_of[devid] = nullptr;
+        side = side_of[devid];
+      }
+      if (side != nullptr && (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+                              hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)) side = nullptr;
+    } }
+  struct EvGuard { hipEvent_t &a, &b; ~EvGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } ev_guard{ev_fork, ev_join};
   for (int J = 0; J < n_pad; J += 4 * NB) {
     const cplx* strip = A + (size_t)J * lda;        // both operands of this group's updates: rows J .. of the matrix itself
     panel(J);
@@ -2301,9 +2316,24 @@ int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long 
       panel(jq);
     }
     if (J + 4 * NB >= n_pad) break;
+    // The right-hand sides' update of the rows below the group streams the group's strips once (bandwidth, a few KB of LDS, few
+    // registers); the K = 256 update of the matrix is bound by the matrix pipe and touches no right-hand-side column: the two run
+    // side by side - the small kernel on a second stream between two events, joined before the next panel (whose strip solve reads
+    // the right-hand-side columns).  BIEM_RHS_SIDE_STREAM=0: one after the other on the caller's stream.
+    const bool beside = rhs_gemv && side != nullptr;
+    if (beside) {
+      BIEM_HIPCHK(hipEventRecord(ev_fork, st));
+      BIEM_HIPCHK(hipStreamWaitEvent(side, ev_fork, 0));
+      // (not in the stage times of biem_profile_*: its interval overlaps the update's; rocprofv3 shows the kernel)
+      hipLaunchKernelGGL(k_rhs_update, dim3((n_pad - (J + 4 * NB) + RHS_UPD_ROWS - 1) / RHS_UPD_ROWS, nb, nrhs), dim3(256), 0, side, A, lda, sys_stride, strip, lda,
+                         sys_stride, n_pad, J + 4 * NB, J, 4 * NB);
+      BIEM_HIPCHK(hipEventRecord(ev_join, side));
+    }
     gemm(st, nb, A, lda, sys_stride, strip, lda, sys_stride, J + 4 * NB, n_pad, J + 4 * NB, n_pad, J, 4 * NB, PK_GEMM, -1.0, nullptr, 0, 0, 0,
          tri_map, true);
-    if (rhs_gemv) {
+    if (beside) {
+      BIEM_HIPCHK(hipStreamWaitEvent(st, ev_join, 0));
+    } else if (rhs_gemv) {
       ProfScope ps(PK_OTHER, st, 0.0);
       hipLaunchKernelGGL(k_rhs_update, dim3((n_pad - (J + 4 * NB) + RHS_UPD_ROWS - 1) / RHS_UPD_ROWS, nb, nrhs), dim3(256), 0, st, A, lda, sys_stride, strip, lda,
                          sys_stride, n_pad, J + 4 * NB, J, 4 * NB);
