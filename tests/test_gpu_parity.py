@@ -1269,13 +1269,14 @@ def test_sym_factor_solve_vs_numpy(lib, N, nb, nrhs):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"BIEM_DIAG_FORM": "step"}, {"BIEM_BACK_FORM": "col"}, {"BIEM_BACK_FORM": "step"}, {"BIEM_BACK_FORM": "row"},
-                                 {"BIEM_DIAG_FORM": "step", "BIEM_BACK_FORM": "row"}])
+                                 {"BIEM_DIAG_FORM": "step", "BIEM_BACK_FORM": "row"}, {"BIEM_RHS_SIDE_STREAM": "0"}])
 @pytest.mark.parametrize("N,nb,nrhs", [(150, 2, 2), (576, 1, 1), (700, 3, 12), (1345, 1, 2), (300, 12, 1), (200, 2, 190)])
 def test_sym_factor_solve_forms(lib, monkeypatch, env, N, nb, nrhs):
     """The forms the row-form factorisation chooses between by the number of systems, forced through the environment: the diagonal
     block with one pivot per barrier (default: four), and the back substitution by rows / by column blocks with a triangular solve
     per diagonal block / by column blocks with the stored inverses of the diagonal blocks (one launch per block, default for up to
-    8 systems).  Same checks as test_sym_factor_solve_vs_numpy."""
+    8 systems); the right-hand sides' update of a group on the caller's stream instead of beside the K = 256 update on a second one.
+    Same checks as test_sym_factor_solve_vs_numpy."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     test_sym_factor_solve_vs_numpy(lib, N, nb, nrhs)
