@@ -2293,8 +2293,12 @@ int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long 
   // second stream + two events for the right-hand sides' update beside the K = 256 update (below); the stream lives per device
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // Default: where this update weighs more than ~2 % of the K = 256 update (its share falls like 1 / N: N < 4096) and for a handful of
+  // systems (latency).  At cfg 3 (N = 6400) it is 1.4 %: overlapping it gains 0.7 % of the step but stretches the K = 256 launches it
+  // co-runs with by 0.6-1.5 % - the dominant kernel's measured rate would carry another kernel's time.  BIEM_RHS_SIDE_STREAM=1 / 0 forces it.
   { const char* es = getenv("BIEM_RHS_SIDE_STREAM");
-    if (rhs_gemv && n_pad > 4 * NB && !(es && es[0] == '0')) {
+    const bool want = es ? es[0] != '0' : (nb <= 8 || n_pad < 4096);
+    if (rhs_gemv && n_pad > 4 * NB && want) {
       static hipStream_t side_of[64] = {nullptr};
       int devid = 0;
       if (hipGetDevice(&devid) == hipSuccess && devid >= 0 && devid < 64) {
@@ -2319,7 +2323,7 @@ int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long 
     // The right-hand sides' update of the rows below the group streams the group's strips once (bandwidth, a few KB of LDS, few
     // registers); the K = 256 update of the matrix is bound by the matrix pipe and touches no right-hand-side column: the two run
     // side by side - the small kernel on a second stream between two events, joined before the next panel (whose strip solve reads
-    // the right-hand-side columns).  BIEM_RHS_SIDE_STREAM=0: one after the other on the caller's stream.
+    // the right-hand-side columns).
     const bool beside = rhs_gemv && side != nullptr;
     if (beside) {
       BIEM_HIPCHK(hipEventRecord(ev_fork, st));

@@ -1269,7 +1269,7 @@ def test_sym_factor_solve_vs_numpy(lib, N, nb, nrhs):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"BIEM_DIAG_FORM": "step"}, {"BIEM_BACK_FORM": "col"}, {"BIEM_BACK_FORM": "step"}, {"BIEM_BACK_FORM": "row"},
-                                 {"BIEM_DIAG_FORM": "step", "BIEM_BACK_FORM": "row"}, {"BIEM_RHS_SIDE_STREAM": "0"}])
+                                 {"BIEM_DIAG_FORM": "step", "BIEM_BACK_FORM": "row"}, {"BIEM_RHS_SIDE_STREAM": "0"}, {"BIEM_RHS_SIDE_STREAM": "1", "BIEM_BACK_FORM": "row"}])
 @pytest.mark.parametrize("N,nb,nrhs", [(150, 2, 2), (576, 1, 1), (700, 3, 12), (1345, 1, 2), (300, 12, 1), (200, 2, 190)])
 def test_sym_factor_solve_forms(lib, monkeypatch, env, N, nb, nrhs):
     """The forms the row-form factorisation chooses between by the number of systems, forced through the environment: the diagonal
