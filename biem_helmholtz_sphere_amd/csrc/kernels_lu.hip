@@ -2293,11 +2293,11 @@ int launch_sym_factor_solve(int nb, int n_pad, int nrhs, double* d_A, long long 
   // second stream + two events for the right-hand sides' update beside the K = 256 update (below); the stream lives per device
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  // Default: where this update weighs more than ~2 % of the K = 256 update (its share falls like 1 / N: N < 4096) and for a handful of
-  // systems (latency).  At cfg 3 (N = 6400) it is 1.4 %: overlapping it gains 0.7 % of the step but stretches the K = 256 launches it
-  // co-runs with by 0.6-1.5 % - the dominant kernel's measured rate would carry another kernel's time.  BIEM_RHS_SIDE_STREAM=1 / 0 forces it.
+  // Opt-in (BIEM_RHS_SIDE_STREAM=1): measured +0.7 % (cfg 3) and +2 % (cfg 5) of the step in alternating runs on one box, but on
+  // another box the K = 256 launches it co-runs with stretched by 6 % (cfg 5: 1643 -> 1612 systems/s) - the update kernel is tuned to
+  // have the CUs to itself - and one system per call pays the two cross-stream dependencies per group (cfg 4: 6.8 -> 7.0 ms).
   { const char* es = getenv("BIEM_RHS_SIDE_STREAM");
-    const bool want = es ? es[0] != '0' : (nb <= 8 || n_pad < 4096);
+    const bool want = es != nullptr && es[0] == '1';
     if (rhs_gemv && n_pad > 4 * NB && want) {
       static hipStream_t side_of[64] = {nullptr};
       int devid = 0;
